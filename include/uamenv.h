@@ -1,0 +1,214 @@
+/*
+ * uamenv.h — C-ABI of the MI355X-native batched single-aircraft guidance /
+ * collision-avoidance environment (libuamenv_hip.so).
+ *
+ * This is the drop-in boundary for the reference's SingleAircraftEnv hot path
+ * (reference citations are relative to the upstream repository root):
+ *
+ *   uam_reset      replaces  SingleAircraftEnv.reset          Simulators/SingleAircraftEnv.py:64-96
+ *   uam_step       replaces  SingleAircraftEnv.step           Simulators/SingleAircraftEnv.py:126-139
+ *                            Ownship.step                     Simulators/SingleAircraftEnv.py:299-309
+ *                            _terminal_reward (sweep + tail)  Simulators/SingleAircraftEnv.py:141-185
+ *                            reset_intruder / random_*        Simulators/SingleAircraftEnv.py:230-251
+ *                            _get_ob (obs pack)               Simulators/SingleAircraftEnv.py:98-124
+ *                  variants  SingleAircraft2Env.step          Simulators/SingleAircraft2Env.py:126-134,294-304
+ *                            MCTSEnv raw obs / pair action    Simulators/SingleAircraftMCTSEnv.py:98-134
+ *                            RandIntruder drift + headings    Simulators/SingleAircraftMCTSRandIntruderEnv.py:124-204,332-336
+ *   batched contract mirrors VecEnv.step_wait / auto-reset    Algorithms/baselines-master/baselines/common/vec_env/dummy_vec_env.py:46-57
+ *   uam_config     snapshots Config                           Simulators/config.py:4-55
+ *
+ * Conventions
+ *   - Plain C, no exceptions cross the boundary.  Every call returns 0 on
+ *     success or a negative errno-style code; uam_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - The library owns only the opaque handle and the struct-of-arrays env
+ *     state it allocates in HBM.  Every in/out buffer of uam_reset/uam_step*
+ *     is a DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()).
+ *     Buffers of uam_get_state/uam_set_state/uam_seed are HOST pointers.
+ *   - uam_reset/uam_step* are asynchronous and stream-ordered on the
+ *     hipStream_t passed as `stream` (NULL = the null stream).
+ *   - A handle is bound to one GPU and is not thread-safe; distinct handles
+ *     (one per GPU / per process) are independent.
+ *   - There is no CPU backend: uam_create fails when no HIP device is usable.
+ */
+#ifndef UAMENV_H
+#define UAMENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAM_ABI_VERSION 1
+
+/* ---- error codes (negative errno values) ---- */
+#define UAM_OK        0
+#define UAM_EINVAL  (-22)
+#define UAM_ENOMEM  (-12)
+#define UAM_EIO      (-5)   /* a HIP runtime call failed; see uam_last_error() */
+#define UAM_ENODEV  (-19)
+
+/* ---- observation layouts (_get_ob variants) ---- */
+enum {
+    UAM_OBS_NORM4 = 0,  /* SingleAircraftEnv.py:98-124: [x/W, y/H, nvx, nvy]*N + own(6) + goal(2), D = 4N+8 */
+    UAM_OBS_RAW4  = 1,  /* SingleAircraftMCTSEnv.py:98-124: raw [x, y, vx, vy]*N + own(6) + goal(2), D = 4N+8 */
+    UAM_OBS_RAW6  = 2   /* SingleAircraftMCTSRandIntruderEnv.py:124-152: raw [x,y,vx,vy,speed,heading]*N + own(6) + goal(2), D = 6N+8 */
+};
+
+/* ---- action encodings ---- */
+enum {
+    UAM_ACT_DISCRETE9   = 0, /* int32[B]; a0 = a/3, a1 = a%3            SingleAircraftEnv.py:128-131 */
+    UAM_ACT_PAIR        = 1, /* int32[B,2]; (a0, a1) used un-decoded     SingleAircraftMCTSEnv.py:126-134 */
+    UAM_ACT_CONTINUOUS1 = 2  /* float32[B]; heading += d_heading*(a-1), no speed command  SingleAircraft2Env.py:294-298 */
+};
+
+/* ---- intruder dynamics ---- */
+enum {
+    UAM_DYN_STRAIGHT     = 0, /* pos += vel                               SingleAircraftEnv.py:148 */
+    UAM_DYN_RANDINTRUDER = 1  /* pos += vel + position_sigma; Bernoulli heading changes after the reward
+                                 SingleAircraftMCTSRandIntruderEnv.py:183,166-174,332-336 */
+};
+
+/* ---- random number source ---- */
+enum {
+    UAM_RNG_PHILOX  = 0, /* counter-based Philox4x32-10 keyed by (seed; env, step, purpose/idx, attempt):
+                            order-free, sharding-invariant; the throughput mode */
+    UAM_RNG_MT19937 = 1  /* one NumPy-legacy MT19937 stream per env, consumed in the reference's draw order
+                            (rk_double / polar rk_gauss with cache).  Env e seeded with s reproduces the
+                            reference run in a process that called np.random.seed(s). */
+};
+
+/* ---- position precision ---- */
+enum {
+    UAM_POS_F32   = 0, /* intruder positions are float32; a rejection redraw (SingleAircraftEnv.py:85-86,236-237)
+                          is rounded to float32 ("rounded mode") */
+    UAM_POS_EXACT = 1  /* positions are stored as float64 with a per-intruder `promoted` bit; un-promoted
+                          intruders use float32 arithmetic, promoted ones the reference's float64 path */
+};
+
+/* ---- info codes written to info_out (the reference's 'result' strings) ---- */
+enum { UAM_INFO_NONE = 0 /* '' */, UAM_INFO_CONFLICT = 1 /* 'c' */, UAM_INFO_GOAL = 2 /* 'g' */, UAM_INFO_NMAC = 3 /* 'n' */ };
+
+/* POD snapshot of Simulators/config.py plus the batch geometry and mode
+ * switches.  Fill with uam_config_default() and then override. */
+typedef struct uam_config {
+    uint32_t struct_size;      /* sizeof(uam_config), ABI check */
+    int32_t  num_envs;         /* B, envs held by THIS handle */
+    int32_t  num_intruders;    /* N (Config.intruder_size), 1..1024 */
+    int32_t  obs_mode;         /* UAM_OBS_* */
+    int32_t  action_mode;      /* UAM_ACT_* */
+    int32_t  dynamics;         /* UAM_DYN_* */
+    int32_t  rng_mode;         /* UAM_RNG_* */
+    int32_t  precision;        /* UAM_POS_* */
+    int32_t  auto_reset;       /* 1: VecEnv semantics, obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
+    int32_t  sparse_reward;    /* Config.sparse_reward */
+    int32_t  random_own_start; /* 1: SingleAircraftRandomEnv.py:70-74 (ownship start drawn like an intruder) */
+    int32_t  reserved0;
+    uint64_t seed;             /* Philox key / default MT19937 seed base (env e gets seed + env_id_offset + e) */
+    int64_t  env_id_offset;    /* global index of local env 0 when the batch is sharded across GPUs */
+
+    double window_width, window_height;                                   /* config.py:6-7   */
+    double minimum_separation, nmac_dist, initial_min_dist, goal_radius;  /* config.py:16-20 */
+    double min_speed, max_speed, d_speed, speed_sigma, position_sigma;    /* config.py:23-27 */
+    double d_heading, heading_sigma;                                      /* config.py:30-31 */
+    double nmac_penalty, conflict_penalty, step_penalty, goal_reward;     /* config.py:37-41 */
+    double dense_reward_div;                                              /* 1200, SingleAircraftEnv.py:185 */
+    double own_x0, own_y0, own_speed0, own_heading0;                      /* SingleAircraftEnv.py:70-74 */
+    double heading_change_prob, heading_change_max_deg;                   /* 0.1, 10: RandIntruderEnv.py:170-173 */
+} uam_config;
+
+/* HOST-side view used by uam_get_state / uam_set_state (checkpoint, parity
+ * injection).  Any pointer may be NULL = skip that field.  Per-intruder
+ * arrays are [B*N] env-major (index e*N + i), per-env arrays are [B]. */
+typedef struct uam_state_view {
+    uint32_t struct_size;
+    int32_t  num_envs, num_intruders;
+    int32_t  reserved0;
+    double  *int_x, *int_y;             /* positions widened to float64 (exact for float32 storage) */
+    float   *int_vx, *int_vy;
+    double  *int_speed, *int_heading;   /* only held when dynamics == RANDINTRUDER or obs_mode == RAW6 */
+    uint8_t *int_conflict;              /* Aircraft.conflict, SingleAircraftEnv.py:279 */
+    uint8_t *int_promoted;              /* 1 = float64 position (rejection redraw), always 0 in UAM_POS_F32 */
+    float   *own_x, *own_y;
+    double  *own_heading, *own_speed, *own_vx, *own_vy;
+    double  *goal_x, *goal_y;
+    int32_t *no_conflict;               /* SingleAircraftEnv.py:94,160 */
+    uint32_t *step_count;               /* per-env counter used in the Philox key */
+    uint32_t *mt_key;                   /* [B*624] MT19937 words, NumPy get_state() layout (UAM_RNG_MT19937) */
+    int32_t  *mt_pos;                   /* [B] */
+    int32_t  *mt_has_gauss;             /* [B] */
+    double   *mt_gauss;                 /* [B] */
+} uam_state_view;
+
+typedef struct uam_env uam_env;
+
+/* Fill *cfg with the shipped Simulators/config.py constants for B envs × N intruders
+ * (discrete-9 actions, normalised obs, Philox RNG, float32 positions, auto_reset on). */
+int uam_config_default(uam_config* cfg, int32_t num_envs, int32_t num_intruders);
+
+/* Width D of one observation row for this config (4N+8 or 6N+8). */
+int32_t uam_obs_dim(const uam_config* cfg);
+
+/* Allocate the env state on GPU `device_id` and seed it.  No episode exists
+ * until uam_reset has run.  Fails with UAM_ENODEV when no HIP device is usable. */
+int uam_create(const uam_config* cfg, int device_id, uam_env** out);
+int uam_destroy(uam_env* env);
+
+/* Re-seed.  seeds_host == NULL: env e gets cfg.seed + env_id_offset + e
+ * (MT19937: low 32 bits, as np.random.seed).  Otherwise one seed per env [B].
+ * Synchronous (host array in). */
+int uam_seed(uam_env* env, const uint64_t* seeds_host);
+
+/* Start new episodes: all envs (mask_dev == NULL) or those with mask_dev[e] != 0.
+ * obs_out: float32[B, D] device, rows of un-masked envs are left untouched; may be NULL. */
+int uam_reset(uam_env* env, const uint8_t* mask_dev, float* obs_out, void* stream);
+
+/* One env.step() for every env of the batch, fused into one kernel launch.
+ *   actions   : device, per uam_config.action_mode
+ *   obs_out   : float32[B, D] device or NULL
+ *   reward_out: float32[B]   device
+ *   done_out  : uint8[B]     device (0/1)
+ *   info_out  : uint8[B]     device (UAM_INFO_*) or NULL */
+int uam_step(uam_env* env, const void* actions, float* obs_out, float* reward_out,
+             uint8_t* done_out, uint8_t* info_out, void* stream);
+
+/* K consecutive steps driven by an action tape [K, B(,2)] without host round
+ * trips.  reward/done/info are [K, B]; obs_out (may be NULL) receives the
+ * observation after the LAST step only.  Needs auto_reset = 1 to be useful. */
+int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_out,
+                  float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
+
+/* Write the current observation of every env without stepping. */
+int uam_observe(uam_env* env, float* obs_out, void* stream);
+
+/* Copy env.no_conflict (int32[B]) to a device buffer. */
+int uam_counters(uam_env* env, int32_t* no_conflict_out_dev, void* stream);
+
+/* Synchronous host<->device state exchange (see uam_state_view). */
+int uam_get_state(uam_env* env, uam_state_view* view);
+int uam_set_state(uam_env* env, const uam_state_view* view);
+
+/* Built-in policies for benchmarks / smoke runs (device, stream-ordered).
+ *   kind 0: uniform random action from Philox(seed=policy_seed; env, call#)
+ *   kind 1: goal-seeking heuristic (turn toward the goal, accelerate)
+ * Writes actions in the handle's action_mode layout to actions_out (device). */
+int uam_policy(uam_env* env, int32_t kind, uint64_t policy_seed, void* actions_out, void* stream);
+
+/* Algorithmic HBM bytes moved by one uam_step over the whole batch (SURVEY §8d
+ * accounting restated for the handle's modes); used for the roofline figure. */
+int64_t uam_step_bytes(const uam_env* env);
+
+/* Average device time in milliseconds per uam_step kernel over the launches
+ * recorded between uam_timing_begin and uam_timing_end (hipEvents on `stream`). */
+int uam_timing_begin(uam_env* env, void* stream);
+int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
+
+const char* uam_last_error(void);
+const char* uam_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAMENV_H */

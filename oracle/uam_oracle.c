@@ -1,0 +1,712 @@
+/*
+ * uam_oracle.c — CPU restatement (plain C) of the reference's SingleAircraftEnv
+ * hot path.  TEST INFRASTRUCTURE ONLY — see uam_oracle.h for the rules and the
+ * parity-pinning statement.  Build: oracle/Makefile (gcc -O2 -ffp-contract=off).
+ *
+ * Every function cites the reference lines it restates (paths relative to the
+ * upstream repository root).  Third-party arithmetic on the path that is not in
+ * the reference tree is restated from its published algorithm:
+ *   - NumPy legacy RandomState (unpinned upstream; NumPy 2.2.6 in the build
+ *     container): MT19937 init_genrand / genrand, rk_double, polar rk_gauss with
+ *     cache, uniform = low + (high-low)*rk_double, normal = loc + scale*gauss.
+ *   - NumPy float32 ufuncs and np.linalg.norm -> BLAS dot on 2-vectors:
+ *     float32: sqrtf(rn(dx*dx) + rn(dy*dy)) (no FMA); float64:
+ *     sqrt(fma(dy,dy,rn(dx*dx))) (OpenBLAS ddot, probed in the build container).
+ *   - gym.spaces.Box.contains (gym <= 0.12 form): shape match and inclusive
+ *     bounds, no dtype clause.
+ *   - NEP-50 scalar promotion for the observation arithmetic.
+ */
+#include "uam_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../gym-guidance-collision-avoidance-single_amd/csrc/uam_pmath.h"
+
+/* ------------------------------------------------------------------ MT19937 */
+/* numpy/random/src/mt19937/mt19937.c (mt19937_seed, mt19937_gen) and
+ * numpy/random/src/legacy/legacy-distributions.c (legacy_gauss). */
+#define MT_N 624
+#define MT_M 397
+typedef struct {
+    uint32_t key[MT_N];
+    int pos;
+    int has_gauss;
+    double gauss;
+} mt_state;
+
+static void mt_seed(mt_state* s, uint32_t seed)
+{
+    for (int pos = 0; pos < MT_N; pos++) {
+        s->key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+    s->pos = MT_N;
+    s->has_gauss = 0;
+    s->gauss = 0.0;
+}
+
+static void mt_twist(mt_state* s)
+{
+    uint32_t y;
+    int i;
+    for (i = 0; i < MT_N - MT_M; i++) {
+        y = (s->key[i] & 0x80000000u) | (s->key[i + 1] & 0x7fffffffu);
+        s->key[i] = s->key[i + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; i < MT_N - 1; i++) {
+        y = (s->key[i] & 0x80000000u) | (s->key[i + 1] & 0x7fffffffu);
+        s->key[i] = s->key[i + (MT_M - MT_N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    y = (s->key[MT_N - 1] & 0x80000000u) | (s->key[0] & 0x7fffffffu);
+    s->key[MT_N - 1] = s->key[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    s->pos = 0;
+}
+
+static uint32_t mt_u32(mt_state* s)
+{
+    if (s->pos == MT_N) mt_twist(s);
+    uint32_t y = s->key[s->pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+static double mt_double(mt_state* s)
+{
+    uint32_t a = mt_u32(s) >> 5, b = mt_u32(s) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+/* ------------------------------------------------------------------ Philox */
+/* Philox4x32-10 (Salmon et al., SC'11), restated independently of the device
+ * implementation in csrc/; keying scheme documented in DESIGN.md. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+enum { PH_OWN_NOISE = 0, PH_SPAWN_POS = 1, PH_SPAWN_SH = 2, PH_RESET_POS = 3, PH_RESET_SH = 4,
+       PH_RESET_GOAL = 5, PH_HEADCHG = 6, PH_RESET_OWN = 8 };
+
+static double u53(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+static double u53_open0(uint32_t a, uint32_t b) /* (0, 1] */
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 1.0) / 9007199254740992.0;
+}
+
+/* ------------------------------------------------------------------ env state */
+typedef struct {
+    double x, y;        /* position value; a float32 value when !promoted */
+    float vx, vy;       /* Aircraft.velocity float32, SingleAircraftEnv.py:277 */
+    double speed, heading;
+    uint8_t conflict;   /* Aircraft.conflict, :279 */
+    uint8_t promoted;   /* position is a float64 array (rejection redraw kept un-cast, :86,:237) */
+} intruder_t;
+
+typedef struct {
+    intruder_t* in;
+    float own_x, own_y;             /* Ownship.position float32 */
+    double own_heading, own_speed;
+    double own_vx, own_vy;          /* Ownship.velocity */
+    int own_v_f32;                  /* velocity is still the float32 array of Aircraft.__init__ (:277) */
+    double goal_x, goal_y;
+    int32_t no_conflict;
+    uint32_t step_count;
+    mt_state* mt;                   /* own stream, or the shared one */
+    int64_t spawns, redraws;
+} env_t;
+
+struct orc_batch {
+    uam_config cfg;
+    int math_impl, shared;
+    int B, N, D;
+    int nthreads;
+    env_t* env;
+    intruder_t* pool;
+    mt_state* mts;
+};
+
+typedef struct { const orc_batch* b; env_t* e; uint32_t gid; } ctx_t;
+
+static void m_sincos(const orc_batch* b, double x, double* s, double* c)
+{
+    if (b->math_impl == ORC_MATH_LIBM) { *s = sin(x); *c = cos(x); }
+    else uam_sincos(x, s, c);
+}
+static double m_log(const orc_batch* b, double x)
+{
+    return b->math_impl == ORC_MATH_LIBM ? log(x) : uam_log(x);
+}
+
+/* legacy_gauss, legacy-distributions.c: polar Box-Muller, returns f*x2 and caches f*x1 */
+static double mt_gauss(const orc_batch* b, mt_state* s)
+{
+    if (s->has_gauss) {
+        double t = s->gauss;
+        s->gauss = 0.0;
+        s->has_gauss = 0;
+        return t;
+    }
+    double f, x1, x2, r2;
+    do {
+        x1 = 2.0 * mt_double(s) - 1.0;
+        x2 = 2.0 * mt_double(s) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = sqrt(-2.0 * m_log(b, r2) / r2);
+    s->gauss = f * x1;
+    s->has_gauss = 1;
+    return f * x2;
+}
+
+static void philox(const ctx_t* c, uint32_t purpose, uint32_t idx, uint32_t attempt, uint32_t out[4])
+{
+    uint32_t ctr[4] = { c->gid, c->e->step_count, (purpose << 16) | idx, attempt };
+    uint32_t key[2] = { (uint32_t)c->b->cfg.seed, (uint32_t)(c->b->cfg.seed >> 32) };
+    orc_philox4x32_10(ctr, key, out);
+}
+
+/* np.linalg.norm(a.position - b.position) for own (float32) vs intruder, SingleAircraftEnv.py:312-313 */
+static double dist_own_intruder(const env_t* e, const intruder_t* it)
+{
+    if (!it->promoted) {
+        float dx = e->own_x - (float)it->x, dy = e->own_y - (float)it->y;
+        float d2 = (float)(dx * dx) + (float)(dy * dy);
+        return (double)sqrtf(d2);
+    }
+    double dx = (double)e->own_x - it->x, dy = (double)e->own_y - it->y;
+    return sqrt(fma(dy, dy, dx * dx));
+}
+
+/* dist(drone, goal): float32 - float64 -> float64, :179,:185 */
+static double dist_own_goal(const env_t* e)
+{
+    double dx = (double)e->own_x - e->goal_x, dy = (double)e->own_y - e->goal_y;
+    return sqrt(fma(dy, dy, dx * dx));
+}
+
+/* reset_intruder / the spawn loop of reset(): SingleAircraftEnv.py:79-86, 230-239, 241-251, 270-279.
+ * reset_phase selects the Philox purpose tags only. */
+static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t* out)
+{
+    const orc_batch* b = c->b;
+    const uam_config* g = &b->cfg;
+    env_t* e = c->e;
+    double px, py, speed, heading;
+    uint32_t w[4];
+    if (g->rng_mode == UAM_RNG_MT19937) {
+        px = 0.0 + g->window_width * mt_double(e->mt);
+        py = 0.0 + g->window_height * mt_double(e->mt);
+        speed = g->min_speed + (g->max_speed - g->min_speed) * mt_double(e->mt);
+        heading = 0.0 + (2.0 * M_PI - 0.0) * mt_double(e->mt);
+    } else {
+        philox(c, reset_phase ? PH_RESET_POS : PH_SPAWN_POS, (uint32_t)idx, 0, w);
+        px = 0.0 + g->window_width * u53(w[0], w[1]);
+        py = 0.0 + g->window_height * u53(w[2], w[3]);
+        philox(c, reset_phase ? PH_RESET_SH : PH_SPAWN_SH, (uint32_t)idx, 0, w);
+        speed = g->min_speed + (g->max_speed - g->min_speed) * u53(w[0], w[1]);
+        heading = 0.0 + (2.0 * M_PI - 0.0) * u53(w[2], w[3]);
+    }
+    double sn, cs;
+    m_sincos(b, heading, &sn, &cs);
+    out->x = (double)(float)px;           /* np.array(position, dtype=np.float32), :272 */
+    out->y = (double)(float)py;
+    out->promoted = 0;
+    out->speed = speed;
+    out->heading = heading;
+    out->vx = (float)(speed * cs);        /* :275-277 */
+    out->vy = (float)(speed * sn);
+    out->conflict = 0;
+    e->spawns++;
+    uint32_t attempt = 0;
+    while (dist_own_intruder(e, out) < g->initial_min_dist) {   /* :85-86, :236-237 */
+        attempt++;
+        if (g->rng_mode == UAM_RNG_MT19937) {
+            px = 0.0 + g->window_width * mt_double(e->mt);
+            py = 0.0 + g->window_height * mt_double(e->mt);
+        } else {
+            philox(c, reset_phase ? PH_RESET_POS : PH_SPAWN_POS, (uint32_t)idx, attempt, w);
+            px = 0.0 + g->window_width * u53(w[0], w[1]);
+            py = 0.0 + g->window_height * u53(w[2], w[3]);
+        }
+        if (g->precision == UAM_POS_EXACT) { out->x = px; out->y = py; out->promoted = 1; }
+        else { out->x = (double)(float)px; out->y = (double)(float)py; }
+        e->redraws++;
+    }
+}
+
+/* SingleAircraftEnv.reset, :64-96 */
+static void env_reset(const ctx_t* c)
+{
+    const uam_config* g = &c->b->cfg;
+    env_t* e = c->e;
+    double sn, cs;
+    double ox = g->own_x0, oy = g->own_y0, osp = g->own_speed0, ohd = g->own_heading0;
+    if (g->random_own_start) {   /* SingleAircraftRandomEnv.py:70-74 */
+        if (g->rng_mode == UAM_RNG_MT19937) {
+            ox = 0.0 + g->window_width * mt_double(e->mt);
+            oy = 0.0 + g->window_height * mt_double(e->mt);
+            osp = g->min_speed + (g->max_speed - g->min_speed) * mt_double(e->mt);
+            ohd = 0.0 + (2.0 * M_PI - 0.0) * mt_double(e->mt);
+        } else {
+            uint32_t w[4];
+            philox(c, PH_RESET_OWN, 0, 0, w);
+            ox = 0.0 + g->window_width * u53(w[0], w[1]);
+            oy = 0.0 + g->window_height * u53(w[2], w[3]);
+            philox(c, PH_RESET_OWN, 1, 0, w);
+            osp = g->min_speed + (g->max_speed - g->min_speed) * u53(w[0], w[1]);
+            ohd = 0.0 + (2.0 * M_PI - 0.0) * u53(w[2], w[3]);
+        }
+    }
+    e->own_x = (float)ox;
+    e->own_y = (float)oy;
+    e->own_speed = osp;
+    e->own_heading = ohd;
+    m_sincos(c->b, ohd, &sn, &cs);
+    e->own_vx = (double)(float)(osp * cs);   /* float32 velocity array of Aircraft.__init__ */
+    e->own_vy = (double)(float)(osp * sn);
+    e->own_v_f32 = 1;
+    for (int i = 0; i < c->b->N; i++) spawn_intruder(c, i, 1, &e->in[i]);
+    if (g->rng_mode == UAM_RNG_MT19937) {    /* Goal(position=self.random_pos()), :91 */
+        e->goal_x = 0.0 + g->window_width * mt_double(e->mt);
+        e->goal_y = 0.0 + g->window_height * mt_double(e->mt);
+    } else {
+        uint32_t w[4];
+        philox(c, PH_RESET_GOAL, 0, 0, w);
+        e->goal_x = 0.0 + g->window_width * u53(w[0], w[1]);
+        e->goal_y = 0.0 + g->window_height * u53(w[2], w[3]);
+    }
+    e->no_conflict = 0;
+    e->step_count++;
+}
+
+/* _get_ob, :98-124 (NORM4); SingleAircraftMCTSEnv.py:98-124 (RAW4);
+ * SingleAircraftMCTSRandIntruderEnv.py:124-152 (RAW6).  NEP-50 arithmetic. */
+static void env_obs(const orc_batch* b, const env_t* e, double* o)
+{
+    const uam_config* g = &b->cfg;
+    const float W32 = (float)g->window_width, H32 = (float)g->window_height;
+    const float vmax32 = (float)g->max_speed, vden32 = (float)(g->max_speed * 2);
+    int k = 0;
+    for (int i = 0; i < b->N; i++) {
+        const intruder_t* it = &e->in[i];
+        if (g->obs_mode == UAM_OBS_NORM4) {
+            if (!it->promoted) { o[k++] = (double)((float)it->x / W32); o[k++] = (double)((float)it->y / H32); }
+            else { o[k++] = it->x / g->window_width; o[k++] = it->y / g->window_height; }
+            o[k++] = (double)((float)(it->vx + vmax32) / vden32);
+            o[k++] = (double)((float)(it->vy + vmax32) / vden32);
+        } else {
+            o[k++] = it->x; o[k++] = it->y; o[k++] = (double)it->vx; o[k++] = (double)it->vy;
+            if (g->obs_mode == UAM_OBS_RAW6) { o[k++] = it->speed; o[k++] = it->heading; }
+        }
+    }
+    if (g->obs_mode == UAM_OBS_NORM4) {
+        o[k++] = (double)(e->own_x / W32);
+        o[k++] = (double)(e->own_y / H32);
+        if (e->own_v_f32) {
+            o[k++] = (double)((float)((float)e->own_vx + vmax32) / vden32);
+            o[k++] = (double)((float)((float)e->own_vy + vmax32) / vden32);
+        } else {
+            o[k++] = (e->own_vx + g->max_speed) / (g->max_speed * 2);
+            o[k++] = (e->own_vy + g->max_speed) / (g->max_speed * 2);
+        }
+        o[k++] = (e->own_speed - g->min_speed) / (g->max_speed - g->min_speed);
+        o[k++] = e->own_heading / (2 * M_PI);
+        o[k++] = e->goal_x / g->window_width;
+        o[k++] = e->goal_y / g->window_height;
+    } else {
+        o[k++] = (double)e->own_x; o[k++] = (double)e->own_y;
+        o[k++] = e->own_vx; o[k++] = e->own_vy;
+        o[k++] = e->own_speed; o[k++] = e->own_heading;
+        o[k++] = e->goal_x; o[k++] = e->goal_y;
+    }
+}
+
+/* Ownship.step, SingleAircraftEnv.py:299-309 (2Env: SingleAircraft2Env.py:294-304) */
+static void own_step(const ctx_t* c, double a0, double a1, int has_speed_cmd)
+{
+    const uam_config* g = &c->b->cfg;
+    env_t* e = c->e;
+    double zh, zs;
+    if (g->rng_mode == UAM_RNG_MT19937) {
+        zh = mt_gauss(c->b, e->mt);
+        /* drawn later in the reference, but nothing else draws in between */
+        e->own_heading += g->d_heading * (a0 - 1.0);
+        e->own_heading += 0.0 + g->heading_sigma * zh;
+        if (has_speed_cmd) e->own_speed += g->d_speed * (a1 - 1.0);
+        e->own_speed = fmax(g->min_speed, fmin(e->own_speed, g->max_speed));
+        zs = mt_gauss(c->b, e->mt);
+        e->own_speed += 0.0 + g->speed_sigma * zs;
+    } else {
+        uint32_t w[4];
+        philox(c, PH_OWN_NOISE, 0, 0, w);
+        double u1 = u53_open0(w[0], w[1]), u2 = u53(w[2], w[3]);
+        double r = sqrt(-2.0 * m_log(c->b, u1));
+        double sn, cs;
+        m_sincos(c->b, 2.0 * M_PI * u2, &sn, &cs);
+        zh = r * cs;
+        zs = r * sn;
+        e->own_heading += g->d_heading * (a0 - 1.0);
+        e->own_heading += 0.0 + g->heading_sigma * zh;
+        if (has_speed_cmd) e->own_speed += g->d_speed * (a1 - 1.0);
+        e->own_speed = fmax(g->min_speed, fmin(e->own_speed, g->max_speed));
+        e->own_speed += 0.0 + g->speed_sigma * zs;
+    }
+    double sn, cs;
+    m_sincos(c->b, e->own_heading, &sn, &cs);
+    e->own_vx = e->own_speed * cs;
+    e->own_vy = e->own_speed * sn;
+    e->own_v_f32 = 0;
+    /* float32 position += float64 velocity: computed in float64, stored float32 */
+    e->own_x = (float)((double)e->own_x + e->own_vx);
+    e->own_y = (float)((double)e->own_y + e->own_vy);
+}
+
+/* _terminal_reward, SingleAircraftEnv.py:141-185 (RandIntruder sweep: ...RandIntruderEnv.py:176-221) */
+static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info)
+{
+    const orc_batch* b = c->b;
+    const uam_config* g = &b->cfg;
+    env_t* e = c->e;
+    int conflict = 0;
+    const float psig32 = (float)g->position_sigma;
+    for (int idx = 0; idx < b->N; idx++) {
+        intruder_t* it = &e->in[idx];
+        intruder_t old;
+        /* intruder.position += intruder.velocity (+ position_sigma), :148 / RandIntruder :183 */
+        float ax = it->vx, ay = it->vy;
+        if (g->dynamics == UAM_DYN_RANDINTRUDER) { ax = (float)(ax + psig32); ay = (float)(ay + psig32); }
+        if (!it->promoted) { it->x = (double)(float)((float)it->x + ax); it->y = (double)(float)((float)it->y + ay); }
+        else { it->x = it->x + (double)ax; it->y = it->y + (double)ay; }
+        double d = dist_own_intruder(e, it);
+        old = *it;
+        /* position_range.contains: inclusive bounds, :151 */
+        int inside = (it->x >= 0.0) && (it->y >= 0.0) && (it->x <= g->window_width) && (it->y <= g->window_height);
+        if (!inside) spawn_intruder(c, idx, 0, it);   /* :152, new object: conflict flag cleared */
+        if (d < g->minimum_separation) {              /* :155 */
+            conflict = 1;
+            if (!old.conflict) {                      /* the OLD object's flag, :159-161 */
+                e->no_conflict += 1;
+                if (inside) it->conflict = 1;         /* flag set on the old object; lost if it was replaced */
+            }
+            if (d < g->nmac_dist) {                   /* :167-168 early exit */
+                *reward = g->nmac_penalty; *done = 1; *info = UAM_INFO_NMAC;
+                return;
+            }
+        }
+    }
+    if (conflict) { *reward = g->conflict_penalty; *done = 0; *info = UAM_INFO_CONFLICT; return; }  /* :171-172 */
+    double dg = dist_own_goal(e);
+    if (dg < g->goal_radius) { *reward = g->goal_reward; *done = 1; *info = UAM_INFO_GOAL; return; } /* :179-180 */
+    if (g->sparse_reward) { *reward = g->step_penalty; *done = 0; *info = UAM_INFO_NONE; return; }   /* :182-183 */
+    *reward = -dg / g->dense_reward_div; *done = 0; *info = UAM_INFO_NONE;                           /* :185 */
+}
+
+/* _update_headings + Aircraft.change_heading, SingleAircraftMCTSRandIntruderEnv.py:166-174, 332-336 */
+static void update_headings(const ctx_t* c)
+{
+    const orc_batch* b = c->b;
+    const uam_config* g = &b->cfg;
+    env_t* e = c->e;
+    for (int i = 0; i < b->N; i++) {
+        double p, ud;
+        int take;
+        if (g->rng_mode == UAM_RNG_MT19937) {
+            p = 0.0 + 1.0 * mt_double(e->mt);
+            take = p < g->heading_change_prob;
+            ud = take ? mt_double(e->mt) : 0.0;
+        } else {
+            uint32_t w[4];
+            philox(c, PH_HEADCHG, (uint32_t)i, 0, w);
+            p = u53(w[0], w[1]);
+            take = p < g->heading_change_prob;
+            ud = u53(w[2], w[3]);
+        }
+        if (take) {
+            double deg = -g->heading_change_max_deg + (g->heading_change_max_deg - (-g->heading_change_max_deg)) * ud;
+            double delta = deg * (M_PI / 180.0);      /* math.radians */
+            intruder_t* it = &e->in[i];
+            it->heading = it->heading + delta;
+            double sn, cs;
+            m_sincos(b, it->heading, &sn, &cs);
+            it->vx = (float)(it->speed * cs);
+            it->vy = (float)(it->speed * sn);
+        }
+    }
+}
+
+/* SingleAircraftEnv.step, :126-139, plus DummyVecEnv auto-reset (dummy_vec_env.py:52-55) */
+static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs, double* reward,
+                     uint8_t* done, uint8_t* info)
+{
+    const orc_batch* b = c->b;
+    const uam_config* g = &b->cfg;
+    double a0 = 1.0, a1 = 1.0;
+    int has_speed = 1;
+    if (g->action_mode == UAM_ACT_DISCRETE9) {
+        int a = ((const int32_t*)actions)[eidx];
+        a0 = (double)(a / 3); a1 = (double)(a % 3);          /* :128-131 */
+    } else if (g->action_mode == UAM_ACT_PAIR) {
+        a0 = (double)((const int32_t*)actions)[2 * eidx];
+        a1 = (double)((const int32_t*)actions)[2 * eidx + 1];
+    } else {
+        a0 = (double)((const float*)actions)[eidx];
+        has_speed = 0;
+    }
+    own_step(c, a0, a1, has_speed);
+    double r; int d, inf;
+    terminal_reward(c, &r, &d, &inf);
+    if (g->dynamics == UAM_DYN_RANDINTRUDER) update_headings(c);
+    c->e->step_count++;
+    if (d && g->auto_reset) env_reset(c);
+    if (obs) env_obs(b, c->e, obs);
+    reward[eidx] = r;
+    done[eidx] = (uint8_t)d;
+    if (info) info[eidx] = (uint8_t)inf;
+}
+
+/* ------------------------------------------------------------------ batch API */
+orc_batch* orc_create(const uam_config* cfg, int math_impl, int shared_stream)
+{
+    if (!cfg || cfg->struct_size != sizeof(uam_config) || cfg->num_envs < 1 || cfg->num_intruders < 1) return NULL;
+    orc_batch* b = (orc_batch*)calloc(1, sizeof(*b));
+    b->cfg = *cfg;
+    b->math_impl = math_impl;
+    b->shared = shared_stream && cfg->rng_mode == UAM_RNG_MT19937;
+    b->B = cfg->num_envs;
+    b->N = cfg->num_intruders;
+    b->D = uam_obs_dim(cfg);
+    b->nthreads = 1;
+    b->env = (env_t*)calloc((size_t)b->B, sizeof(env_t));
+    b->pool = (intruder_t*)calloc((size_t)b->B * b->N, sizeof(intruder_t));
+    int nmt = cfg->rng_mode == UAM_RNG_MT19937 ? (b->shared ? 1 : b->B) : 0;
+    b->mts = nmt ? (mt_state*)calloc((size_t)nmt, sizeof(mt_state)) : NULL;
+    for (int e = 0; e < b->B; e++) {
+        b->env[e].in = b->pool + (size_t)e * b->N;
+        b->env[e].mt = nmt ? &b->mts[b->shared ? 0 : e] : NULL;
+    }
+    orc_seed(b, NULL);
+    return b;
+}
+
+void orc_destroy(orc_batch* b)
+{
+    if (!b) return;
+    free(b->env); free(b->pool); free(b->mts); free(b);
+}
+
+int orc_seed(orc_batch* b, const uint64_t* seeds)
+{
+    if (b->cfg.rng_mode == UAM_RNG_MT19937) {
+        int n = b->shared ? 1 : b->B;
+        for (int e = 0; e < n; e++) {
+            uint64_t s = seeds ? seeds[e] : b->cfg.seed + (uint64_t)b->cfg.env_id_offset + (uint64_t)e;
+            mt_seed(&b->mts[e], (uint32_t)s);
+        }
+    } else if (seeds) {
+        b->cfg.seed = seeds[0];
+    }
+    for (int e = 0; e < b->B; e++) b->env[e].step_count = 0;
+    return 0;
+}
+
+void orc_set_threads(orc_batch* b, int nthreads) { b->nthreads = nthreads < 1 ? 1 : nthreads; }
+
+void orc_reset(orc_batch* b, const uint8_t* mask, double* obs_out)
+{
+    int par = !b->shared && b->nthreads > 1;
+    (void)par;
+#pragma omp parallel for schedule(static) num_threads(b->nthreads) if (par)
+    for (int e = 0; e < b->B; e++) {
+        if (mask && !mask[e]) continue;
+        ctx_t c = { b, &b->env[e], (uint32_t)((uint64_t)b->cfg.env_id_offset + (uint64_t)e) };
+        env_reset(&c);
+        if (obs_out) env_obs(b, &b->env[e], obs_out + (size_t)e * b->D);
+    }
+}
+
+void orc_step(orc_batch* b, const void* actions, double* obs_out, double* reward_out,
+              uint8_t* done_out, uint8_t* info_out)
+{
+    int par = !b->shared && b->nthreads > 1;
+    (void)par;
+#pragma omp parallel for schedule(static) num_threads(b->nthreads) if (par)
+    for (int e = 0; e < b->B; e++) {
+        ctx_t c = { b, &b->env[e], (uint32_t)((uint64_t)b->cfg.env_id_offset + (uint64_t)e) };
+        env_step(&c, e, actions, obs_out ? obs_out + (size_t)e * b->D : NULL, reward_out, done_out, info_out);
+    }
+}
+
+void orc_observe(orc_batch* b, double* obs_out)
+{
+    for (int e = 0; e < b->B; e++) env_obs(b, &b->env[e], obs_out + (size_t)e * b->D);
+}
+
+int64_t orc_spawn_count(const orc_batch* b)
+{
+    int64_t s = 0;
+    for (int e = 0; e < b->B; e++) s += b->env[e].spawns;
+    return s;
+}
+int64_t orc_redraw_count(const orc_batch* b)
+{
+    int64_t s = 0;
+    for (int e = 0; e < b->B; e++) s += b->env[e].redraws;
+    return s;
+}
+
+void orc_get_state(orc_batch* b, uam_state_view* v)
+{
+    for (int e = 0; e < b->B; e++) {
+        const env_t* en = &b->env[e];
+        for (int i = 0; i < b->N; i++) {
+            size_t k = (size_t)e * b->N + i;
+            const intruder_t* it = &en->in[i];
+            if (v->int_x) v->int_x[k] = it->x;
+            if (v->int_y) v->int_y[k] = it->y;
+            if (v->int_vx) v->int_vx[k] = it->vx;
+            if (v->int_vy) v->int_vy[k] = it->vy;
+            if (v->int_speed) v->int_speed[k] = it->speed;
+            if (v->int_heading) v->int_heading[k] = it->heading;
+            if (v->int_conflict) v->int_conflict[k] = it->conflict;
+            if (v->int_promoted) v->int_promoted[k] = it->promoted;
+        }
+        if (v->own_x) v->own_x[e] = en->own_x;
+        if (v->own_y) v->own_y[e] = en->own_y;
+        if (v->own_heading) v->own_heading[e] = en->own_heading;
+        if (v->own_speed) v->own_speed[e] = en->own_speed;
+        if (v->own_vx) v->own_vx[e] = en->own_vx;
+        if (v->own_vy) v->own_vy[e] = en->own_vy;
+        if (v->goal_x) v->goal_x[e] = en->goal_x;
+        if (v->goal_y) v->goal_y[e] = en->goal_y;
+        if (v->no_conflict) v->no_conflict[e] = en->no_conflict;
+        if (v->step_count) v->step_count[e] = en->step_count;
+        if (b->mts && !b->shared) {
+            const mt_state* m = en->mt;
+            if (v->mt_key) memcpy(v->mt_key + (size_t)e * MT_N, m->key, sizeof(m->key));
+            if (v->mt_pos) v->mt_pos[e] = m->pos;
+            if (v->mt_has_gauss) v->mt_has_gauss[e] = m->has_gauss;
+            if (v->mt_gauss) v->mt_gauss[e] = m->gauss;
+        }
+    }
+}
+
+void orc_set_state(orc_batch* b, const uam_state_view* v)
+{
+    for (int e = 0; e < b->B; e++) {
+        env_t* en = &b->env[e];
+        for (int i = 0; i < b->N; i++) {
+            size_t k = (size_t)e * b->N + i;
+            intruder_t* it = &en->in[i];
+            if (v->int_x) it->x = v->int_x[k];
+            if (v->int_y) it->y = v->int_y[k];
+            if (v->int_vx) it->vx = v->int_vx[k];
+            if (v->int_vy) it->vy = v->int_vy[k];
+            if (v->int_speed) it->speed = v->int_speed[k];
+            if (v->int_heading) it->heading = v->int_heading[k];
+            if (v->int_conflict) it->conflict = v->int_conflict[k];
+            if (v->int_promoted) it->promoted = v->int_promoted[k];
+        }
+        if (v->own_x) en->own_x = v->own_x[e];
+        if (v->own_y) en->own_y = v->own_y[e];
+        if (v->own_heading) en->own_heading = v->own_heading[e];
+        if (v->own_speed) en->own_speed = v->own_speed[e];
+        if (v->own_vx) { en->own_vx = v->own_vx[e]; en->own_v_f32 = 0; }
+        if (v->own_vy) en->own_vy = v->own_vy[e];
+        if (v->goal_x) en->goal_x = v->goal_x[e];
+        if (v->goal_y) en->goal_y = v->goal_y[e];
+        if (v->no_conflict) en->no_conflict = v->no_conflict[e];
+        if (v->step_count) en->step_count = v->step_count[e];
+        if (b->mts && !b->shared) {
+            mt_state* m = en->mt;
+            if (v->mt_key) memcpy(m->key, v->mt_key + (size_t)e * MT_N, sizeof(m->key));
+            if (v->mt_pos) m->pos = v->mt_pos[e];
+            if (v->mt_has_gauss) m->has_gauss = v->mt_has_gauss[e];
+            if (v->mt_gauss) m->gauss = v->mt_gauss[e];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ known-answer helpers */
+void orc_np_seed_random_sample(uint32_t seed, int n, double* out)
+{
+    mt_state s;
+    mt_seed(&s, seed);
+    for (int i = 0; i < n; i++) out[i] = mt_double(&s);
+}
+
+void orc_np_seed_normal(uint32_t seed, int n, double loc, double scale, double* out)
+{
+    mt_state s;
+    orc_batch fake;
+    memset(&fake, 0, sizeof(fake));
+    fake.math_impl = ORC_MATH_LIBM;
+    mt_seed(&s, seed);
+    for (int i = 0; i < n; i++) out[i] = loc + scale * mt_gauss(&fake, &s);
+}
+
+void orc_np_seed_state(uint32_t seed, int ndraw, uint32_t* key624, int* pos)
+{
+    mt_state s;
+    mt_seed(&s, seed);
+    for (int i = 0; i < ndraw; i++) (void)mt_double(&s);
+    memcpy(key624, s.key, sizeof(s.key));
+    *pos = s.pos;
+}
+
+void orc_pmath_sincos(double x, double* s, double* c) { uam_sincos(x, s, c); }
+double orc_pmath_log(double x) { return uam_log(x); }
+
+/* ------------------------------------------------------------------ config helpers
+ * (restated here so the oracle does not link the product library) */
+#ifndef UAM_ORACLE_NO_CONFIG
+int32_t uam_obs_dim(const uam_config* cfg)
+{
+    return (cfg->obs_mode == UAM_OBS_RAW6 ? 6 : 4) * cfg->num_intruders + 8;
+}
+
+/* Simulators/config.py:4-55 */
+int uam_config_default(uam_config* c, int32_t B, int32_t N)
+{
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->num_envs = B; c->num_intruders = N;
+    c->obs_mode = UAM_OBS_NORM4; c->action_mode = UAM_ACT_DISCRETE9; c->dynamics = UAM_DYN_STRAIGHT;
+    c->rng_mode = UAM_RNG_PHILOX; c->precision = UAM_POS_F32; c->auto_reset = 1;
+    const double scale = 30.0;
+    c->window_width = 800; c->window_height = 800;
+    c->minimum_separation = 555 / scale; c->nmac_dist = 150 / scale;
+    c->initial_min_dist = 3000 / scale; c->goal_radius = 600 / scale;
+    c->min_speed = 50 / scale; c->max_speed = 80 / scale; c->d_speed = 5 / scale;
+    c->speed_sigma = 2 / scale; c->position_sigma = 10 / scale;
+    c->d_heading = 5 * (M_PI / 180.0); c->heading_sigma = 4 * (M_PI / 180.0);
+    c->nmac_penalty = -10 / 10.0; c->conflict_penalty = -5 / 10.0; c->step_penalty = -0.01 / 10.0;
+    c->goal_reward = 10 / 10.0; c->dense_reward_div = 1200;
+    c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = M_PI / 4;
+    c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
+    return 0;
+}
+#endif

@@ -1,0 +1,48 @@
+"""Helpers shared by the golden-fixture tests (oracle- and GPU-side)."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TRAJECTORY_FIXTURES = [
+    "g1_discrete9_n4_seed0", "g2_goalseek_n8_seed3", "g2_goalseek_n32_seed1", "g2_goalseek_n80_seed4",
+    "g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal",
+    "g8_continuous_n8_seed7", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
+    "g9b_mctsenv_n8_seed11",
+]
+
+STATE_KEYS = ["int_x", "int_y", "int_vx", "int_vy", "int_speed", "int_heading", "int_conflict", "int_promoted",
+              "own_x", "own_y", "own_heading", "own_speed", "own_vx", "own_vy", "goal_x", "goal_y", "no_conflict"]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+
+
+def all_fixture_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def config_overrides(fx, **extra):
+    """uam_config field overrides encoded in a fixture's meta_* entries."""
+    over = dict(obs_mode=int(fx["meta_obs_mode"]), action_mode=int(fx["meta_action_mode"]),
+                dynamics=int(fx["meta_dynamics"]), seed=int(fx["meta_seed"]))
+    for k in ("heading_sigma", "speed_sigma"):
+        if "meta_" + k in fx:
+            over[k] = float(fx["meta_" + k])
+    over.update(extra)
+    return over
+
+
+def prefixed_state(fx, prefix, idx=None):
+    """{field: array shaped [1, ...]} from st0_/inj_/st_ entries (idx selects a row of st_*)."""
+    st = {}
+    for k in STATE_KEYS:
+        key = prefix + k
+        if key not in fx:
+            continue
+        v = fx[key] if idx is None else fx[key][idx]
+        st[k] = np.ascontiguousarray(np.asarray(v)[None, ...])
+    return st
