@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched SingleAircraftEnv.step() on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is ONE fused uam_step launch over the whole per-GPU batch (BASELINE.json configs[2]:
+discrete-9, 65536 envs x 32 intruders, the configuration the metric is quoted on).  Inputs (env
+state, action tape) are resident in HBM before the timed region; observations, rewards and dones
+stay on the device.  With N>1 every rank owns 65536 envs (weak scaling, env_id_offset = rank*B so
+the union is one consistent batch) and the per-chunk reward/done slabs are all-gathered with RCCL.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : algorithmic HBM bytes per launch / average launch duration (hipEvents on the
+                 launch stream) against the 8 TB/s HBM3E peak,
+  cpu_baseline : the CPU oracle (a port of the reference's step()) timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+B_PER_GPU = 65536
+N_INTRUDERS = 32
+TAPE_LEN = 64
+GATHER_EVERY = 32
+
+
+def cpu_baseline(nthreads, seconds_target=12.0):
+    """Oracle (kind 'port') on a bounded sample: same env config, random actions, all host threads."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    B, N = 8192, N_INTRUDERS
+    cfg = oracle.default_config(B, N, rng_mode=oracle.RNG_PHILOX, precision=oracle.POS_F32, auto_reset=1, seed=0)
+    env = oracle.OracleBatch(cfg, oracle.MATH_PORTABLE, threads=nthreads)
+    env.reset(want_obs=False)
+    rs = np.random.RandomState(1)
+    acts = rs.randint(0, 9, size=(TAPE_LEN, B)).astype(np.int32)
+    for k in range(3):
+        env.step(acts[k], want_obs=True)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for k in range(10):
+            env.step(acts[(steps + k) % TAPE_LEN], want_obs=True)
+        steps += 10
+        el = time.perf_counter() - t0
+        if el >= seconds_target or steps >= 2000:
+            break
+    env.close()
+    return {"value": B * steps / el, "unit": "env-steps/s", "cores": nthreads, "kind": "port",
+            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, %d steps, random actions, "
+                      "float64 obs written" % (B, N, steps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="envs per GPU")
+    ap.add_argument("--intruders", type=int, default=N_INTRUDERS)
+    ap.add_argument("--policy", default="random", choices=["random", "goal"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import uamenv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    B, N = args.batch, args.intruders
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="discrete9", rng="philox", precision="f32", seed=0,
+                                          auto_reset=True, device=local_rank, env_id_offset=rank * B)
+    dev = env.device
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    tape = torch.randint(0, 9, (TAPE_LEN, B), dtype=torch.int32, device=dev, generator=gen)
+    rew_slab = torch.empty((GATHER_EVERY, B), dtype=torch.float32, device=dev)
+    done_slab = torch.empty((GATHER_EVERY, B), dtype=torch.uint8, device=dev)
+    if world > 1:
+        rew_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.float32, device=dev)
+        done_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.uint8, device=dev)
+    acts = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def run(nsteps, offset=0):
+        for k in range(nsteps):
+            i = offset + k
+            if args.policy == "goal":
+                a = env.policy_actions("goal", out=acts)
+            else:
+                a = tape[i % TAPE_LEN]
+            obs, rew, done, _ = env.step(a)
+            if world > 1:
+                j = i % GATHER_EVERY
+                rew_slab[j].copy_(rew)
+                done_slab[j].copy_(env._done)
+                if j == GATHER_EVERY - 1:
+                    # the one exchange of the path: reward/done slabs of the chunk, gathered over xGMI
+                    dist.all_gather_into_tensor(rew_all, rew_slab)
+                    dist.all_gather_into_tensor(done_all, done_slab)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    env.timing_begin()
+    t0 = time.perf_counter()
+    run(args.steps, offset=args.warmup)
+    kernel_ms = env.timing_end()      # hipEvents on the launch stream, averaged over the uam_step launches
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_env_steps = float(B) * world * args.steps
+        value = total_env_steps / elapsed
+        step_bytes = env.step_bytes
+        achieved = step_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU "
+                                   "(BASELINE.json configs[2], roofline run)" % (B, N),
+                       "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": "philox",
+                       "positions": "float32", "obs": "float32[B,%d] written every step" % env.obs_dim,
+                       "exchange": "none" if world == 1 else "all_gather(reward,done) every %d steps" % GATHER_EVERY},
+            "pair_steps_per_sec": value * N,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "uam_step_kernel<f32,philox,straight>", "bytes_per_launch": step_bytes,
+                         "avg_launch_ms": kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))
+            except Exception as ex:   # the checker must never take the measurement down
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (ex,)}
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

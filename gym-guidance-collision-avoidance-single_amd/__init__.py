@@ -1,0 +1,18 @@
+"""MI355X-native batched single-aircraft guidance / collision-avoidance env.
+
+The directory name carries the upstream project's name; import it as `uamenv`
+(the sibling `uamenv/` package aliases this directory).  Only the hot path of
+the reference lives here: HIP kernels + C-ABI (`csrc/`) and the host-side mirror
+of the env interface (`envs.py`).
+"""
+from . import _capi
+from ._capi import UamError, build, default_config
+from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2Env, SingleAircraftEnv,
+                   SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv, make_config)
+from . import spaces
+
+__all__ = [
+    "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
+    "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv", "make_config",
+    "UamError", "build", "default_config", "spaces",
+]

@@ -1,0 +1,669 @@
+/*
+ * uamenv.hip — host side of libuamenv_hip.so: the extern "C" boundary declared
+ * in include/uamenv.h.  Owns the opaque handle and the SoA env state in HBM,
+ * validates operand shapes before every launch, and dispatches the templated
+ * gfx950 kernels of uam_device.h.  No torch types, no CPU fallback.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "uam_device.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(UAM_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct uam_env {
+    uam_config cfg;
+    int device;
+    int Np, Q, L, lshift, T, E, D, hold_sh;
+    UamDev s;
+    std::vector<void*> allocs;
+    hipEvent_t ev0, ev1;
+    bool timing;
+    int64_t timed_launches;
+    uint32_t policy_calls;
+};
+
+extern "C" const char* uam_last_error(void) { return g_err; }
+extern "C" const char* uam_version(void) { return "uamenv-hip 0.1 (gfx950, abi 1)"; }
+
+extern "C" int32_t uam_obs_dim(const uam_config* cfg)
+{
+    return (cfg->obs_mode == UAM_OBS_RAW6 ? 6 : 4) * cfg->num_intruders + 8;
+}
+
+/* Simulators/config.py:4-55 */
+extern "C" int uam_config_default(uam_config* c, int32_t B, int32_t N)
+{
+    if (!c) return fail(UAM_EINVAL, "cfg is NULL");
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->num_envs = B;
+    c->num_intruders = N;
+    c->obs_mode = UAM_OBS_NORM4;
+    c->action_mode = UAM_ACT_DISCRETE9;
+    c->dynamics = UAM_DYN_STRAIGHT;
+    c->rng_mode = UAM_RNG_PHILOX;
+    c->precision = UAM_POS_F32;
+    c->auto_reset = 1;
+    const double scale = 30.0, pi = 3.14159265358979323846;
+    c->window_width = 800; c->window_height = 800;
+    c->minimum_separation = 555 / scale; c->nmac_dist = 150 / scale;
+    c->initial_min_dist = 3000 / scale; c->goal_radius = 600 / scale;
+    c->min_speed = 50 / scale; c->max_speed = 80 / scale; c->d_speed = 5 / scale;
+    c->speed_sigma = 2 / scale; c->position_sigma = 10 / scale;
+    c->d_heading = 5 * (pi / 180.0); c->heading_sigma = 4 * (pi / 180.0);
+    c->nmac_penalty = -10 / 10.0; c->conflict_penalty = -5 / 10.0; c->step_penalty = -0.01 / 10.0;
+    c->goal_reward = 10 / 10.0; c->dense_reward_div = 1200;
+    c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = pi / 4;
+    c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
+    return UAM_OK;
+}
+
+static int validate(const uam_config* c)
+{
+    if (!c) return fail(UAM_EINVAL, "cfg is NULL");
+    if (c->struct_size != sizeof(uam_config))
+        return fail(UAM_EINVAL, "uam_config.struct_size %u != %zu (ABI mismatch)", c->struct_size, sizeof(uam_config));
+    if (c->num_envs < 1) return fail(UAM_EINVAL, "num_envs must be >= 1 (got %d)", c->num_envs);
+    if (c->num_intruders < 1 || c->num_intruders > 256)
+        return fail(UAM_EINVAL, "num_intruders must be in 1..256 (got %d)", c->num_intruders);
+    if ((int64_t)c->num_envs * ((c->num_intruders + 3) & ~3) > (int64_t)1 << 31)
+        return fail(UAM_EINVAL, "num_envs*num_intruders too large for one handle");
+    if (c->obs_mode < 0 || c->obs_mode > UAM_OBS_RAW6) return fail(UAM_EINVAL, "bad obs_mode %d", c->obs_mode);
+    if (c->action_mode < 0 || c->action_mode > UAM_ACT_CONTINUOUS1) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
+    if (c->dynamics < 0 || c->dynamics > UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "bad dynamics %d", c->dynamics);
+    if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
+    if (c->precision < 0 || c->precision > UAM_POS_EXACT) return fail(UAM_EINVAL, "bad precision %d", c->precision);
+    if (!(c->window_width > 0) || !(c->window_height > 0)) return fail(UAM_EINVAL, "window must be positive");
+    if (!(c->max_speed > c->min_speed)) return fail(UAM_EINVAL, "max_speed must exceed min_speed");
+    if (!(c->initial_min_dist >= 0) || c->initial_min_dist * 2 >= fmin(c->window_width, c->window_height))
+        return fail(UAM_EINVAL, "initial_min_dist leaves no room to spawn (rejection loop would not end)");
+    return UAM_OK;
+}
+
+template <typename T>
+static int dev_alloc(uam_env* e, T** out, size_t count)
+{
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t err = hipMalloc(&p, bytes);
+    if (err != hipSuccess) return fail(UAM_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    err = hipMemset(p, 0, bytes);
+    if (err != hipSuccess) { (void)hipFree(p); return fail(UAM_EIO, "hipMemset failed: %s", hipGetErrorString(err)); }
+    e->allocs.push_back(p);
+    *out = (T*)p;
+    return UAM_OK;
+}
+
+static void fill_params(const uam_env* e, UamParams* p)
+{
+    const uam_config& c = e->cfg;
+    memset(p, 0, sizeof(*p));
+    p->s = e->s;
+    p->B = c.num_envs; p->N = c.num_intruders; p->Np = e->Np; p->Q = e->Q; p->L = e->L; p->lshift = e->lshift;
+    p->E = e->E; p->D = e->D;
+    p->obs_mode = c.obs_mode; p->action_mode = c.action_mode; p->auto_reset = c.auto_reset;
+    p->sparse_reward = c.sparse_reward; p->random_own_start = c.random_own_start;
+    p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
+    p->hold_sh = e->hold_sh;
+    p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
+    p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
+    p->W = c.window_width; p->H = c.window_height; p->min_sep = c.minimum_separation; p->nmac = c.nmac_dist;
+    p->init_min = c.initial_min_dist; p->goal_r = c.goal_radius; p->min_speed = c.min_speed; p->max_speed = c.max_speed;
+    p->d_speed = c.d_speed; p->speed_sigma = c.speed_sigma; p->d_heading = c.d_heading; p->heading_sigma = c.heading_sigma;
+    p->nmac_pen = c.nmac_penalty; p->conf_pen = c.conflict_penalty; p->step_pen = c.step_penalty;
+    p->goal_rew = c.goal_reward; p->dense_div = c.dense_reward_div;
+    p->own_x0 = c.own_x0; p->own_y0 = c.own_y0; p->own_speed0 = c.own_speed0; p->own_heading0 = c.own_heading0;
+    p->hc_prob = c.heading_change_prob; p->hc_max_deg = c.heading_change_max_deg;
+    p->W32 = (float)c.window_width; p->H32 = (float)c.window_height;
+    p->vmax32 = (float)c.max_speed; p->vden32 = (float)(c.max_speed * 2);
+    p->psig32 = (float)c.position_sigma;
+    p->min_sep32 = (float)c.minimum_separation; p->nmac32 = (float)c.nmac_dist; p->init_min32 = (float)c.initial_min_dist;
+}
+
+static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
+static inline size_t lds_of(const uam_env* e) { return (size_t)e->E * sizeof(EnvShare); }
+
+extern "C" int uam_seed(uam_env* e, const uint64_t* seeds);
+
+extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
+{
+    if (!out) return fail(UAM_EINVAL, "out is NULL");
+    *out = nullptr;
+    int rc = validate(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t err = hipGetDeviceCount(&ndev);
+    if (err != hipSuccess || ndev < 1)
+        return fail(UAM_ENODEV, "no HIP device available (%s); this library has no CPU backend",
+                    err == hipSuccess ? "device count 0" : hipGetErrorString(err));
+    if (device_id < 0 || device_id >= ndev) return fail(UAM_ENODEV, "device_id %d out of range (0..%d)", device_id, ndev - 1);
+    HIP_TRY(hipSetDevice(device_id));
+
+    uam_env* e = new uam_env();
+    e->cfg = *cfg;
+    e->device = device_id;
+    e->timing = false;
+    e->timed_launches = 0;
+    e->policy_calls = 0;
+    e->ev0 = nullptr; e->ev1 = nullptr;
+    const int B = cfg->num_envs, N = cfg->num_intruders;
+    e->Np = (N + 3) & ~3;
+    e->Q = e->Np / 4;
+    int L = 1, ls = 0;
+    while (L < e->Q) { L <<= 1; ls++; }
+    e->L = L; e->lshift = ls;
+    /* block size: as large as 512 while the grid still has >= 1024 blocks (4 per CU), never below a wave */
+    int T = UAM_MAX_BLOCK;
+    while (T > 64 && T > L && ((int64_t)B * L + T - 1) / T < 1024) T >>= 1;
+    if (T < L) T = L;
+    if (T < 64) T = 64;
+    e->T = T;
+    e->E = T / L;
+    e->D = uam_obs_dim(cfg);
+    e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
+
+    const size_t BI = (size_t)B * e->Np;
+    memset(&e->s, 0, sizeof(e->s));
+    rc = UAM_OK;
+    if (cfg->precision == UAM_POS_EXACT) {
+        double *x = nullptr, *y = nullptr;
+        if (!rc) rc = dev_alloc(e, &x, BI);
+        if (!rc) rc = dev_alloc(e, &y, BI);
+        e->s.px = x; e->s.py = y;
+    } else {
+        float *x = nullptr, *y = nullptr;
+        if (!rc) rc = dev_alloc(e, &x, BI);
+        if (!rc) rc = dev_alloc(e, &y, BI);
+        e->s.px = x; e->s.py = y;
+    }
+    if (!rc) rc = dev_alloc(e, &e->s.vx, BI);
+    if (!rc) rc = dev_alloc(e, &e->s.vy, BI);
+    if (e->hold_sh) {
+        if (!rc) rc = dev_alloc(e, &e->s.isp, BI);
+        if (!rc) rc = dev_alloc(e, &e->s.ihd, BI);
+    }
+    if (!rc) rc = dev_alloc(e, &e->s.qf, BI / 4);
+    if (!rc) rc = dev_alloc(e, &e->s.own_x, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.own_y, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.own_h, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.own_s, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.own_vx, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.own_vy, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.goal_x, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.goal_y, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.step_count, (size_t)B);
+    if (cfg->rng_mode == UAM_RNG_MT19937) {
+        if (!rc) rc = dev_alloc(e, &e->s.mt_key, (size_t)B * UAM_MT_N);
+        if (!rc) rc = dev_alloc(e, &e->s.mt_pos, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.mt_gen, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.mt_has_gauss, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.mt_gauss, (size_t)B);
+    }
+    if (!rc && hipEventCreate(&e->ev0) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
+    if (!rc && hipEventCreate(&e->ev1) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
+    if (!rc) rc = uam_seed(e, nullptr);
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        uam_destroy(e);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    *out = e;
+    return UAM_OK;
+}
+
+extern "C" int uam_destroy(uam_env* e)
+{
+    if (!e) return UAM_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    delete e;
+    return UAM_OK;
+}
+
+/* np.random.seed(int): mt19937_seed (numpy/random/src/mt19937/mt19937.c) */
+static void mt_init_genrand(uint32_t seed, uint32_t* key)
+{
+    for (int pos = 0; pos < UAM_MT_N; pos++) {
+        key[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+}
+
+extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int B = e->cfg.num_envs;
+    if (e->cfg.rng_mode == UAM_RNG_MT19937) {
+        std::vector<uint32_t> keys((size_t)B * UAM_MT_N);
+        std::vector<int32_t> pos((size_t)B, UAM_MT_N), zero((size_t)B, 0);
+        std::vector<double> zd((size_t)B, 0.0);
+        for (int i = 0; i < B; i++) {
+            uint64_t s = seeds ? seeds[i] : e->cfg.seed + (uint64_t)e->cfg.env_id_offset + (uint64_t)i;
+            mt_init_genrand((uint32_t)s, &keys[(size_t)i * UAM_MT_N]);
+        }
+        HIP_TRY(hipMemcpy(e->s.mt_key, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.mt_pos, pos.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.mt_gen, pos.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.mt_has_gauss, zero.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.mt_gauss, zd.data(), (size_t)B * 8, hipMemcpyHostToDevice));
+    } else if (seeds) {
+        e->cfg.seed = seeds[0];
+    }
+    HIP_TRY(hipMemset(e->s.step_count, 0, (size_t)B * 4));
+    return UAM_OK;
+}
+
+/* ---- kernel dispatch over (precision, rng, dynamics) ---- */
+template <bool POS64, int RNG>
+static void launch_step_ri(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER)
+        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, true>), grid, block, lds_of(e), st, p);
+    else
+        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false>), grid, block, lds_of(e), st, p);
+}
+
+static void launch_step(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
+    if (x && mt) launch_step_ri<true, UAM_RNG_MT19937>(e, p, st);
+    else if (x) launch_step_ri<true, UAM_RNG_PHILOX>(e, p, st);
+    else if (mt) launch_step_ri<false, UAM_RNG_MT19937>(e, p, st);
+    else launch_step_ri<false, UAM_RNG_PHILOX>(e, p, st);
+}
+
+static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
+    if (x && mt) hipLaunchKernelGGL((uam_reset_kernel<true, UAM_RNG_MT19937>), grid, block, 0, st, p);
+    else if (x) hipLaunchKernelGGL((uam_reset_kernel<true, UAM_RNG_PHILOX>), grid, block, 0, st, p);
+    else if (mt) hipLaunchKernelGGL((uam_reset_kernel<false, UAM_RNG_MT19937>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((uam_reset_kernel<false, UAM_RNG_PHILOX>), grid, block, 0, st, p);
+}
+
+static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)
+{
+    if (obs && ((uintptr_t)obs & 3u)) return fail(UAM_EINVAL, "obs_out must be 4-byte aligned");
+    p->obs_vec = (obs && (e->D % 4 == 0) && (((uintptr_t)obs & 15u) == 0)) ? 1 : 0;
+    return UAM_OK;
+}
+
+extern "C" int uam_reset(uam_env* e, const uint8_t* mask_dev, float* obs_out, void* stream)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    UamParams p;
+    fill_params(e, &p);
+    int rc = check_obs_ptr(e, obs_out, &p);
+    if (rc) return rc;
+    p.mask = mask_dev;
+    p.obs = obs_out;
+    launch_reset(e, p, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+static int step_once(uam_env* e, const void* actions, float* obs_out, float* reward_out, uint8_t* done_out,
+                     uint8_t* info_out, hipStream_t st)
+{
+    UamParams p;
+    fill_params(e, &p);
+    int rc = check_obs_ptr(e, obs_out, &p);
+    if (rc) return rc;
+    p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
+    launch_step(e, p, st);
+    HIP_TRY(hipGetLastError());
+    if (e->timing) e->timed_launches++;
+    return UAM_OK;
+}
+
+static int check_step_args(const uam_env* e, const void* actions, const float* reward_out, const uint8_t* done_out)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    if (!actions) return fail(UAM_EINVAL, "actions is NULL");
+    if (!reward_out || !done_out) return fail(UAM_EINVAL, "reward_out and done_out are required");
+    const uintptr_t am = e->cfg.action_mode == UAM_ACT_PAIR ? 7u : 3u;
+    if ((uintptr_t)actions & am) return fail(UAM_EINVAL, "actions pointer is not aligned for action_mode %d", e->cfg.action_mode);
+    if ((uintptr_t)reward_out & 3u) return fail(UAM_EINVAL, "reward_out must be 4-byte aligned");
+    return UAM_OK;
+}
+
+extern "C" int uam_step(uam_env* e, const void* actions, float* obs_out, float* reward_out, uint8_t* done_out,
+                        uint8_t* info_out, void* stream)
+{
+    int rc = check_step_args(e, actions, reward_out, done_out);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    return step_once(e, actions, obs_out, reward_out, done_out, info_out, (hipStream_t)stream);
+}
+
+extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,
+                             uint8_t* done_out, uint8_t* info_out, void* stream)
+{
+    int rc = check_step_args(e, action_tape, reward_out, done_out);
+    if (rc) return rc;
+    if (K < 1) return fail(UAM_EINVAL, "K must be >= 1 (got %d)", K);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t B = (size_t)e->cfg.num_envs;
+    const size_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    for (int k = 0; k < K; k++) {
+        const void* a = (const char*)action_tape + (size_t)k * B * abytes;
+        rc = step_once(e, a, k == K - 1 ? obs_out : nullptr, reward_out + (size_t)k * B, done_out + (size_t)k * B,
+                       info_out ? info_out + (size_t)k * B : nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return UAM_OK;
+}
+
+extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    if (!obs_out) return fail(UAM_EINVAL, "obs_out is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    UamParams p;
+    fill_params(e, &p);
+    int rc = check_obs_ptr(e, obs_out, &p);
+    if (rc) return rc;
+    p.obs = obs_out;
+    dim3 grid(grid_of(e)), block(e->T);
+    if (e->cfg.precision == UAM_POS_EXACT) hipLaunchKernelGGL((uam_observe_kernel<true>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((uam_observe_kernel<false>), grid, block, 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+extern "C" int uam_counters(uam_env* e, int32_t* no_conflict_out_dev, void* stream)
+{
+    if (!e || !no_conflict_out_dev) return fail(UAM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(no_conflict_out_dev, e->s.no_conflict, (size_t)e->cfg.num_envs * 4, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return UAM_OK;
+}
+
+extern "C" int uam_policy(uam_env* e, int32_t kind, uint64_t policy_seed, void* actions_out, void* stream)
+{
+    if (!e || !actions_out) return fail(UAM_EINVAL, "NULL argument");
+    if (kind < 0 || kind > 1) return fail(UAM_EINVAL, "unknown policy kind %d", kind);
+    HIP_TRY(hipSetDevice(e->device));
+    UamParams p;
+    fill_params(e, &p);
+    p.policy_kind = kind;
+    p.policy_lo = (uint32_t)policy_seed; p.policy_hi = (uint32_t)(policy_seed >> 32);
+    p.policy_call = e->policy_calls++;
+    p.actions_out = actions_out;
+    const int T = 256;
+    hipLaunchKernelGGL(uam_policy_kernel, dim3((e->cfg.num_envs + T - 1) / T), dim3(T), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+extern "C" int64_t uam_step_bytes(const uam_env* e)
+{
+    if (!e) return 0;
+    const int64_t posb = e->cfg.precision == UAM_POS_EXACT ? 8 : 4;
+    const int64_t obs_w = e->cfg.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
+    /* per intruder: x,y read + write, vx,vy read, obs write (+ speed,heading read when held);
+     * per env: SURVEY §8d's 150 B (ownship, goal, flags, counters, action, obs tail, reward/done/info) */
+    const int64_t per_int = 4 * posb + 8 + 4 * obs_w + (e->hold_sh ? 16 : 0);
+    return (int64_t)e->cfg.num_envs * (per_int * e->cfg.num_intruders + 150);
+}
+
+extern "C" int uam_timing_begin(uam_env* e, void* stream)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    e->timing = true;
+    e->timed_launches = 0;
+    HIP_TRY(hipEventRecord(e->ev0, (hipStream_t)stream));
+    return UAM_OK;
+}
+
+extern "C" int uam_timing_end(uam_env* e, void* stream, float* elapsed_ms_out)
+{
+    if (!e || !elapsed_ms_out) return fail(UAM_EINVAL, "NULL argument");
+    if (!e->timing) return fail(UAM_EINVAL, "uam_timing_begin was not called");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventRecord(e->ev1, (hipStream_t)stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->timing = false;
+    *elapsed_ms_out = e->timed_launches > 0 ? ms / (float)e->timed_launches : ms;
+    return UAM_OK;
+}
+
+/* ---- host <-> device state exchange ---- */
+template <typename T>
+static int d2h(std::vector<T>& v, const T* dev, size_t n)
+{
+    v.resize(n);
+    HIP_TRY(hipMemcpy(v.data(), dev, n * sizeof(T), hipMemcpyDeviceToHost));
+    return UAM_OK;
+}
+
+static int check_view(const uam_env* e, const uam_state_view* v)
+{
+    if (!e || !v) return fail(UAM_EINVAL, "NULL argument");
+    if (v->struct_size != sizeof(uam_state_view)) return fail(UAM_EINVAL, "uam_state_view.struct_size mismatch");
+    if (v->num_envs != e->cfg.num_envs || v->num_intruders != e->cfg.num_intruders)
+        return fail(UAM_EINVAL, "state view is [%d,%d] but the env is [%d,%d]", v->num_envs, v->num_intruders,
+                    e->cfg.num_envs, e->cfg.num_intruders);
+    return UAM_OK;
+}
+
+extern "C" int uam_get_state(uam_env* e, uam_state_view* v)
+{
+    int rc = check_view(e, v);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int B = e->cfg.num_envs, N = e->cfg.num_intruders, Np = e->Np;
+    const size_t BI = (size_t)B * Np;
+    if (v->int_x || v->int_y) {
+        if (e->cfg.precision == UAM_POS_EXACT) {
+            std::vector<double> x, y;
+            if ((rc = d2h(x, (const double*)e->s.px, BI)) || (rc = d2h(y, (const double*)e->s.py, BI))) return rc;
+            for (int b = 0; b < B; b++)
+                for (int i = 0; i < N; i++) {
+                    if (v->int_x) v->int_x[(size_t)b * N + i] = x[(size_t)b * Np + i];
+                    if (v->int_y) v->int_y[(size_t)b * N + i] = y[(size_t)b * Np + i];
+                }
+        } else {
+            std::vector<float> x, y;
+            if ((rc = d2h(x, (const float*)e->s.px, BI)) || (rc = d2h(y, (const float*)e->s.py, BI))) return rc;
+            for (int b = 0; b < B; b++)
+                for (int i = 0; i < N; i++) {
+                    if (v->int_x) v->int_x[(size_t)b * N + i] = (double)x[(size_t)b * Np + i];
+                    if (v->int_y) v->int_y[(size_t)b * N + i] = (double)y[(size_t)b * Np + i];
+                }
+        }
+    }
+    if (v->int_vx || v->int_vy) {
+        std::vector<float> x, y;
+        if ((rc = d2h(x, e->s.vx, BI)) || (rc = d2h(y, e->s.vy, BI))) return rc;
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                if (v->int_vx) v->int_vx[(size_t)b * N + i] = x[(size_t)b * Np + i];
+                if (v->int_vy) v->int_vy[(size_t)b * N + i] = y[(size_t)b * Np + i];
+            }
+    }
+    if ((v->int_speed || v->int_heading) && e->hold_sh) {
+        std::vector<double> x, y;
+        if ((rc = d2h(x, e->s.isp, BI)) || (rc = d2h(y, e->s.ihd, BI))) return rc;
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                if (v->int_speed) v->int_speed[(size_t)b * N + i] = x[(size_t)b * Np + i];
+                if (v->int_heading) v->int_heading[(size_t)b * N + i] = y[(size_t)b * Np + i];
+            }
+    }
+    if (v->int_conflict || v->int_promoted) {
+        std::vector<uint8_t> f;
+        if ((rc = d2h(f, e->s.qf, BI / 4))) return rc;
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                const uint8_t q = f[((size_t)b * Np + i) >> 2];
+                if (v->int_conflict) v->int_conflict[(size_t)b * N + i] = (q >> (i & 3)) & 1u;
+                if (v->int_promoted) v->int_promoted[(size_t)b * N + i] = (q >> (4 + (i & 3))) & 1u;
+            }
+    }
+#define GET_ENV(field, src) \
+    if (v->field) HIP_TRY(hipMemcpy(v->field, e->s.src, (size_t)B * sizeof(*v->field), hipMemcpyDeviceToHost))
+    GET_ENV(own_x, own_x); GET_ENV(own_y, own_y); GET_ENV(own_heading, own_h); GET_ENV(own_speed, own_s);
+    GET_ENV(own_vx, own_vx); GET_ENV(own_vy, own_vy); GET_ENV(goal_x, goal_x); GET_ENV(goal_y, goal_y);
+    GET_ENV(no_conflict, no_conflict); GET_ENV(step_count, step_count);
+#undef GET_ENV
+    if (e->cfg.rng_mode == UAM_RNG_MT19937) {
+        if (v->mt_key || v->mt_pos) {
+            /* export in NumPy's get_state() form: finish the lazily twisted round on the host copy */
+            std::vector<uint32_t> key;
+            std::vector<int32_t> pos, gen;
+            if ((rc = d2h(key, e->s.mt_key, (size_t)B * UAM_MT_N)) || (rc = d2h(pos, e->s.mt_pos, (size_t)B)) ||
+                (rc = d2h(gen, e->s.mt_gen, (size_t)B)))
+                return rc;
+            for (int b = 0; b < B; b++) {
+                uint32_t* k = &key[(size_t)b * UAM_MT_N];
+                if (pos[b] < UAM_MT_N) {
+                    for (int i = gen[b]; i < UAM_MT_N; i++) {
+                        const int p1 = i + 1 == UAM_MT_N ? 0 : i + 1;
+                        int pm = i + UAM_MT_M; if (pm >= UAM_MT_N) pm -= UAM_MT_N;
+                        const uint32_t y = (k[i] & 0x80000000u) | (k[p1] & 0x7fffffffu);
+                        k[i] = k[pm] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    }
+                }
+            }
+            if (v->mt_key) memcpy(v->mt_key, key.data(), key.size() * 4);
+            if (v->mt_pos) memcpy(v->mt_pos, pos.data(), (size_t)B * 4);
+        }
+        if (v->mt_has_gauss) HIP_TRY(hipMemcpy(v->mt_has_gauss, e->s.mt_has_gauss, (size_t)B * 4, hipMemcpyDeviceToHost));
+        if (v->mt_gauss) HIP_TRY(hipMemcpy(v->mt_gauss, e->s.mt_gauss, (size_t)B * 8, hipMemcpyDeviceToHost));
+    }
+    return UAM_OK;
+}
+
+extern "C" int uam_set_state(uam_env* e, const uam_state_view* v)
+{
+    int rc = check_view(e, v);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int B = e->cfg.num_envs, N = e->cfg.num_intruders, Np = e->Np;
+    const size_t BI = (size_t)B * Np;
+    if (v->int_x || v->int_y) {
+        if (!(v->int_x && v->int_y)) return fail(UAM_EINVAL, "int_x and int_y must be given together");
+        if (e->cfg.precision == UAM_POS_EXACT) {
+            std::vector<double> x(BI, 0.0), y(BI, 0.0);
+            for (int b = 0; b < B; b++)
+                for (int i = 0; i < N; i++) {
+                    x[(size_t)b * Np + i] = v->int_x[(size_t)b * N + i];
+                    y[(size_t)b * Np + i] = v->int_y[(size_t)b * N + i];
+                }
+            HIP_TRY(hipMemcpy(e->s.px, x.data(), BI * 8, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(e->s.py, y.data(), BI * 8, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> x(BI, 0.f), y(BI, 0.f);
+            for (int b = 0; b < B; b++)
+                for (int i = 0; i < N; i++) {
+                    x[(size_t)b * Np + i] = (float)v->int_x[(size_t)b * N + i];
+                    y[(size_t)b * Np + i] = (float)v->int_y[(size_t)b * N + i];
+                }
+            HIP_TRY(hipMemcpy(e->s.px, x.data(), BI * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(e->s.py, y.data(), BI * 4, hipMemcpyHostToDevice));
+        }
+    }
+    if (v->int_vx || v->int_vy) {
+        if (!(v->int_vx && v->int_vy)) return fail(UAM_EINVAL, "int_vx and int_vy must be given together");
+        std::vector<float> x(BI, 0.f), y(BI, 0.f);
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                x[(size_t)b * Np + i] = v->int_vx[(size_t)b * N + i];
+                y[(size_t)b * Np + i] = v->int_vy[(size_t)b * N + i];
+            }
+        HIP_TRY(hipMemcpy(e->s.vx, x.data(), BI * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.vy, y.data(), BI * 4, hipMemcpyHostToDevice));
+    }
+    if ((v->int_speed || v->int_heading) && e->hold_sh) {
+        if (!(v->int_speed && v->int_heading)) return fail(UAM_EINVAL, "int_speed and int_heading must be given together");
+        std::vector<double> x(BI, 0.0), y(BI, 0.0);
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                x[(size_t)b * Np + i] = v->int_speed[(size_t)b * N + i];
+                y[(size_t)b * Np + i] = v->int_heading[(size_t)b * N + i];
+            }
+        HIP_TRY(hipMemcpy(e->s.isp, x.data(), BI * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->s.ihd, y.data(), BI * 8, hipMemcpyHostToDevice));
+    }
+    if (v->int_conflict || v->int_promoted) {
+        std::vector<uint8_t> f;
+        if ((rc = d2h(f, e->s.qf, BI / 4))) return rc;
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < N; i++) {
+                uint8_t& q = f[((size_t)b * Np + i) >> 2];
+                if (v->int_conflict) {
+                    q &= (uint8_t)~(1u << (i & 3));
+                    q |= (uint8_t)((v->int_conflict[(size_t)b * N + i] ? 1u : 0u) << (i & 3));
+                }
+                if (v->int_promoted) {
+                    q &= (uint8_t)~(1u << (4 + (i & 3)));
+                    const bool pr = v->int_promoted[(size_t)b * N + i] != 0;
+                    if (pr && e->cfg.precision != UAM_POS_EXACT)
+                        return fail(UAM_EINVAL, "promoted intruders need precision = UAM_POS_EXACT");
+                    q |= (uint8_t)((pr ? 1u : 0u) << (4 + (i & 3)));
+                }
+            }
+        HIP_TRY(hipMemcpy(e->s.qf, f.data(), BI / 4, hipMemcpyHostToDevice));
+    }
+#define SET_ENV(field, dst) \
+    if (v->field) HIP_TRY(hipMemcpy(e->s.dst, v->field, (size_t)B * sizeof(*v->field), hipMemcpyHostToDevice))
+    SET_ENV(own_x, own_x); SET_ENV(own_y, own_y); SET_ENV(own_heading, own_h); SET_ENV(own_speed, own_s);
+    SET_ENV(own_vx, own_vx); SET_ENV(own_vy, own_vy); SET_ENV(goal_x, goal_x); SET_ENV(goal_y, goal_y);
+    SET_ENV(no_conflict, no_conflict); SET_ENV(step_count, step_count);
+#undef SET_ENV
+    if (e->cfg.rng_mode == UAM_RNG_MT19937) {
+        if (v->mt_key || v->mt_pos) {
+            if (!(v->mt_key && v->mt_pos)) return fail(UAM_EINVAL, "mt_key and mt_pos must be given together");
+            /* NumPy form: every word of the round is already twisted */
+            std::vector<int32_t> gen((size_t)B, UAM_MT_N);
+            HIP_TRY(hipMemcpy(e->s.mt_key, v->mt_key, (size_t)B * UAM_MT_N * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(e->s.mt_pos, v->mt_pos, (size_t)B * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(e->s.mt_gen, gen.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        }
+        if (v->mt_has_gauss) HIP_TRY(hipMemcpy(e->s.mt_has_gauss, v->mt_has_gauss, (size_t)B * 4, hipMemcpyHostToDevice));
+        if (v->mt_gauss) HIP_TRY(hipMemcpy(e->s.mt_gauss, v->mt_gauss, (size_t)B * 8, hipMemcpyHostToDevice));
+    }
+    return UAM_OK;
+}

@@ -1,0 +1,374 @@
+"""Host-side mirror of the reference's env interface over the HIP C-ABI.
+
+Two shapes, same kernels:
+
+* `BatchedSingleAircraftEnv` — VecEnv-shaped (baselines/common/vec_env/__init__.py:26-105):
+  `num_envs`, `reset() -> obs[B, D]`, `step_async/step_wait/step -> (obs, rews, dones, infos)`,
+  auto-reset on done (dummy_vec_env.py:52-55).  Observations, rewards and dones are torch
+  tensors that stay on the GPU; `infos` is materialised lazily.
+* `SingleAircraftEnv` & variants — gym.Env duck types with the reference's signatures
+  (Simulators/SingleAircraftEnv.py:27-139): `reset() -> obs`, `step(a) -> (obs, reward, done,
+  {'result': code})`, attributes `observation_space`, `action_space`, `no_conflict`,
+  `intruder_size`.  They default to the NumPy-compatible MT19937 stream and exact float64
+  promotion, so `env.seed(s)` reproduces the reference run under `np.random.seed(s)`.
+
+PyTorch is used only for device buffers and streams.  There is no CPU path: constructing an
+env without the built library or without a GPU raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi as capi
+from . import spaces
+
+
+class Config:
+    """Editable mirror of Simulators/config.py:4-55; snapshotted into `uam_config` when an env is built."""
+    window_width = 800
+    window_height = 800
+    diagonal = 800
+    intruder_size = 80
+    EPISODES = 1000
+    G = 9.8
+    tick = 30
+    scale = 30
+    minimum_separation = 555 / scale
+    NMAC_dist = 150 / scale
+    horizon_dist = 4000 / scale
+    initial_min_dist = 3000 / scale
+    goal_radius = 600 / scale
+    min_speed = 50 / scale
+    max_speed = 80 / scale
+    d_speed = 5 / scale
+    speed_sigma = 2 / scale
+    position_sigma = 10 / scale
+    d_heading = math.radians(5)
+    heading_sigma = math.radians(4)
+    max_steps = 1000
+    NMAC_penalty = -10 / 10
+    conflict_penalty = -5 / 10
+    wall_penalty = -5 / 10
+    step_penalty = -0.01 / 10
+    goal_reward = 10 / 10
+    sparse_reward = False
+    conflict_coeff = 0.00025
+    n = 4
+
+
+_VARIANTS = {
+    # name: (obs_mode, action_mode, dynamics, random_own_start)
+    "discrete9": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 0),    # Simulators/SingleAircraftEnv.py
+    "continuous": (capi.OBS_NORM4, capi.ACT_CONTINUOUS1, capi.DYN_STRAIGHT, 0),  # Simulators/SingleAircraft2Env.py
+    "mcts": (capi.OBS_RAW4, capi.ACT_PAIR, capi.DYN_STRAIGHT, 0),                # Simulators/SingleAircraftMCTSEnv.py
+    "randintruder": (capi.OBS_RAW6, capi.ACT_PAIR, capi.DYN_RANDINTRUDER, 0),    # ...MCTSRandIntruderEnv.py
+    "random_start": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),  # Simulators/SingleAircraftRandomEnv.py
+}
+_RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
+_PREC = {"f32": capi.POS_F32, "exact": capi.POS_EXACT}
+
+
+def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox", precision="f32", seed=0,
+                auto_reset=True, env_id_offset=0, config=Config, **overrides):
+    """Build a `uam_config` from the (possibly edited) `Config` class plus explicit field overrides."""
+    obs_mode, action_mode, dynamics, ros = _VARIANTS[variant]
+    n = int(config.intruder_size if num_intruders is None else num_intruders)
+    cfg = capi.default_config(
+        int(num_envs), n, obs_mode=obs_mode, action_mode=action_mode, dynamics=dynamics, random_own_start=ros,
+        rng_mode=_RNG[rng], precision=_PREC[precision], auto_reset=int(bool(auto_reset)),
+        seed=int(seed) & 0xFFFFFFFFFFFFFFFF, env_id_offset=int(env_id_offset),
+        sparse_reward=int(bool(config.sparse_reward)),
+        window_width=config.window_width, window_height=config.window_height,
+        minimum_separation=config.minimum_separation, nmac_dist=config.NMAC_dist,
+        initial_min_dist=config.initial_min_dist, goal_radius=config.goal_radius,
+        min_speed=config.min_speed, max_speed=config.max_speed, d_speed=config.d_speed,
+        speed_sigma=config.speed_sigma, position_sigma=config.position_sigma,
+        d_heading=config.d_heading, heading_sigma=config.heading_sigma,
+        nmac_penalty=config.NMAC_penalty, conflict_penalty=config.conflict_penalty,
+        step_penalty=config.step_penalty, goal_reward=config.goal_reward,
+        own_speed0=config.min_speed)
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError("uam_config has no field %r" % k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+class LazyInfos:
+    """Sequence of `{'result': code}` dicts (SingleAircraftEnv.py:139) backed by the device code tensor."""
+
+    def __init__(self, codes, as_dict=True):
+        self.codes = codes
+        self._as_dict = as_dict
+        self._host = None
+
+    def _h(self):
+        if self._host is None:
+            self._host = self.codes.cpu().numpy()
+        return self._host
+
+    def __len__(self):
+        return int(self.codes.shape[0])
+
+    def __getitem__(self, i):
+        code = capi.INFO_CODES[int(self._h()[i])]
+        return {"result": code} if self._as_dict else code
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def copy(self):
+        return list(self)
+
+
+class BatchedSingleAircraftEnv:
+    """B envs stepped by one fused HIP kernel per `step`; VecEnv-shaped."""
+
+    def __init__(self, num_envs, num_intruders=None, variant="discrete9", rng="philox", precision="f32", seed=0,
+                 auto_reset=True, device=None, env_id_offset=0, config=Config, cfg=None, **overrides):
+        import torch
+        self._torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("uamenv needs a HIP GPU (torch.cuda.is_available() is False); there is no CPU backend")
+        self._lib = capi.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device if isinstance(device, int) else torch.device(device).index or 0))
+        self.cfg = cfg if cfg is not None else make_config(
+            num_envs, num_intruders, variant, rng, precision, seed, auto_reset, env_id_offset, config, **overrides)
+        self.num_envs = int(self.cfg.num_envs)
+        self.intruder_size = int(self.cfg.num_intruders)
+        self.obs_dim = capi.obs_dim(self.cfg)
+        # observation_space advertises 4N+8 even for the 6-wide RandIntruder obs (RandIntruderEnv.py:51-52)
+        self.observation_space = spaces.Box(low=-1000, high=1000, shape=(self.intruder_size * 4 + 8,), dtype=np.float32)
+        if self.cfg.action_mode == capi.ACT_CONTINUOUS1:
+            self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float64)
+        else:
+            self.action_space = spaces.Discrete(9)
+        self._h = C.c_void_p()
+        capi.check(self._lib.uam_create(C.byref(self.cfg), self.device.index, C.byref(self._h)))
+        B, D = self.num_envs, self.obs_dim
+        with torch.cuda.device(self.device):
+            self._obs = torch.empty((B, D), dtype=torch.float32, device=self.device)
+            self._rew = torch.empty((B,), dtype=torch.float32, device=self.device)
+            self._done = torch.empty((B,), dtype=torch.uint8, device=self.device)
+            self._info = torch.empty((B,), dtype=torch.uint8, device=self.device)
+        self._pending = None
+        self.closed = False
+
+    # ---- plumbing
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _as_actions(self, actions):
+        torch = self._torch
+        am = self.cfg.action_mode
+        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.as_tensor(np.asarray(actions), dtype=dt)
+        a = actions.to(device=self.device, dtype=dt).contiguous()
+        want = self.num_envs * (2 if am == capi.ACT_PAIR else 1)
+        if a.numel() != want:
+            raise ValueError("actions has %d elements, expected %d for %d envs" % (a.numel(), want, self.num_envs))
+        return a
+
+    def close(self):
+        if not self.closed and self._h:
+            self._lib.uam_destroy(self._h)
+            self._h = C.c_void_p()
+        self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- VecEnv API
+    def seed(self, seeds=None):
+        """Re-seed: one seed per env (array) or None for cfg.seed + global env index."""
+        arr = None if seeds is None else np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.num_envs,)))
+        capi.check(self._lib.uam_seed(self._h, None if arr is None else arr.ctypes.data))
+        return seeds
+
+    def reset(self, mask=None):
+        torch = self._torch
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+        capi.check(self._lib.uam_reset(self._h, None if m is None else m.data_ptr(), self._obs.data_ptr(), self._stream()))
+        return self._obs
+
+    def step_async(self, actions):
+        if self._pending is not None:
+            raise RuntimeError("already running an async step")
+        a = self._as_actions(actions)
+        capi.check(self._lib.uam_step(self._h, a.data_ptr(), self._obs.data_ptr(), self._rew.data_ptr(),
+                                      self._done.data_ptr(), self._info.data_ptr(), self._stream()))
+        self._pending = a   # keep the action buffer alive until the kernel has consumed it
+
+    def step_wait(self):
+        if self._pending is None:
+            raise RuntimeError("not running an async step")
+        self._pending = None
+        return self._obs, self._rew, self._done.bool(), LazyInfos(self._info)
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def step_many(self, action_tape, want_obs=True):
+        """K steps from an action tape [K, B(,2)] with no host round trips; returns
+        (obs after the last step, rewards [K,B], dones [K,B] uint8, info codes [K,B] uint8)."""
+        torch = self._torch
+        am = self.cfg.action_mode
+        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        tape = torch.as_tensor(action_tape).to(device=self.device, dtype=dt).contiguous()
+        K = int(tape.shape[0])
+        if tape.numel() != K * self.num_envs * (2 if am == capi.ACT_PAIR else 1):
+            raise ValueError("action tape has the wrong shape %s" % (tuple(tape.shape),))
+        rew = torch.empty((K, self.num_envs), dtype=torch.float32, device=self.device)
+        done = torch.empty((K, self.num_envs), dtype=torch.uint8, device=self.device)
+        info = torch.empty((K, self.num_envs), dtype=torch.uint8, device=self.device)
+        capi.check(self._lib.uam_step_many(self._h, K, tape.data_ptr(), self._obs.data_ptr() if want_obs else None,
+                                           rew.data_ptr(), done.data_ptr(), info.data_ptr(), self._stream()))
+        return self._obs, rew, done, info
+
+    def observe(self):
+        capi.check(self._lib.uam_observe(self._h, self._obs.data_ptr(), self._stream()))
+        return self._obs
+
+    def policy_actions(self, kind="random", seed=1, out=None):
+        """Device-side action generator for benchmarks: 'random' or 'goal' (turn to goal, accelerate)."""
+        torch = self._torch
+        am = self.cfg.action_mode
+        if out is None:
+            shape = (self.num_envs, 2) if am == capi.ACT_PAIR else (self.num_envs,)
+            out = torch.empty(shape, dtype=torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32, device=self.device)
+        capi.check(self._lib.uam_policy(self._h, {"random": 0, "goal": 1}[kind], int(seed), out.data_ptr(), self._stream()))
+        return out
+
+    @property
+    def no_conflict(self):
+        out = self._torch.empty((self.num_envs,), dtype=self._torch.int32, device=self.device)
+        capi.check(self._lib.uam_counters(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    @property
+    def step_bytes(self):
+        return int(self._lib.uam_step_bytes(self._h))
+
+    def timing_begin(self):
+        capi.check(self._lib.uam_timing_begin(self._h, self._stream()))
+
+    def timing_end(self):
+        ms = C.c_float(0)
+        capi.check(self._lib.uam_timing_end(self._h, self._stream(), C.byref(ms)))
+        return float(ms.value)
+
+    # ---- state exchange (checkpoint / parity injection)
+    def get_state(self, fields=None):
+        B, N = self.num_envs, self.intruder_size
+        names = list(capi.STATE_FIELDS) if fields is None else list(fields)
+        if self.cfg.rng_mode != capi.RNG_MT19937:
+            names = [n for n in names if not n.startswith("mt_")]
+        hold_sh = self.cfg.dynamics == capi.DYN_RANDINTRUDER or self.cfg.obs_mode == capi.OBS_RAW6
+        if not hold_sh:
+            names = [n for n in names if n not in ("int_speed", "int_heading")]
+        st = {}
+        for n in names:
+            dt, shape = capi.STATE_FIELDS[n]
+            st[n] = np.zeros({"B": (B,), "BN": (B, N), "B624": (B, 624)}[shape], dtype=dt)
+        v = capi.make_view(st, B, N)
+        capi.check(self._lib.uam_get_state(self._h, C.byref(v)))
+        return st
+
+    def set_state(self, st):
+        B, N = self.num_envs, self.intruder_size
+        arrs = {}
+        for n, a in st.items():
+            dt, _ = capi.STATE_FIELDS[n]
+            arrs[n] = np.ascontiguousarray(a, dtype=dt)
+        v = capi.make_view(arrs, B, N)
+        capi.check(self._lib.uam_set_state(self._h, C.byref(v)))
+
+
+class SingleAircraftEnv:
+    """Drop-in for Simulators/SingleAircraftEnv.py (one env, NumPy in/out, gym signatures)."""
+    _variant = "discrete9"
+    _info_as_dict = True
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, num_intruders=None, seed=None, device=None, rng="mt19937", precision="exact", config=Config,
+                 **overrides):
+        self._seed = 2 if seed is None else int(seed)   # the reference calls self.seed(2) in __init__ (:41)
+        self._vec = BatchedSingleAircraftEnv(1, num_intruders, self._variant, rng, precision, self._seed,
+                                             auto_reset=False, device=device, config=config, **overrides)
+        self.intruder_size = self._vec.intruder_size
+        self.observation_space = self._vec.observation_space
+        self.action_space = self._vec.action_space
+        self.window_width, self.window_height = config.window_width, config.window_height
+        self.viewer = None
+        self.state = None
+
+    def seed(self, seed=None):
+        """Unlike the reference (whose per-env np_random is never used, :43-45) this really seeds the env:
+        seed(s) ≙ np.random.seed(s) in the reference's process."""
+        self._seed = int(seed) if seed is not None else 0
+        self._vec.seed([self._seed])
+        return [seed]
+
+    def _obs_np(self, t):
+        return t[0].cpu().numpy().astype(np.float64)
+
+    def reset(self):
+        return self._obs_np(self._vec.reset())
+
+    def _encode_action(self, action):
+        return [int(action)]
+
+    def step(self, action):
+        obs, rew, done, infos = self._vec.step(self._encode_action(action))
+        return self._obs_np(obs), float(rew[0].item()), bool(done[0].item()), \
+            LazyInfos(infos.codes, self._info_as_dict)[0]
+
+    @property
+    def no_conflict(self):
+        return int(self._vec.no_conflict[0].item())
+
+    def render(self, mode="human"):
+        return None   # no display on the GPU box; SURVEY §2 #8 (out of scope)
+
+    def close(self):
+        self._vec.close()
+
+
+class SingleAircraft2Env(SingleAircraftEnv):
+    """Simulators/SingleAircraft2Env.py: continuous action, heading += d_heading*(a-1), no speed command."""
+    _variant = "continuous"
+
+    def _encode_action(self, action):
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        assert a.shape == (1,) and -1 <= a[0] <= 1, "given action is in incorrect shape"   # :127
+        return np.asarray([a[0]], dtype=np.float32)
+
+
+class SingleAircraftMCTSEnv(SingleAircraftEnv):
+    """Simulators/SingleAircraftMCTSEnv.py: raw observation, (a0, a1) pair action."""
+    _variant = "mcts"
+
+    def _encode_action(self, action):
+        return np.asarray([[int(action[0]), int(action[1])]], dtype=np.int32)
+
+
+class SingleAircraftMCTSRandIntruderEnv(SingleAircraftMCTSEnv):
+    """Simulators/SingleAircraftMCTSRandIntruderEnv.py: drifting intruders with random heading changes,
+    raw 6-wide observation, info returned as a bare string (:164)."""
+    _variant = "randintruder"
+    _info_as_dict = False
+
+
+class SingleAircraftRandomEnv(SingleAircraftEnv):
+    """Simulators/SingleAircraftRandomEnv.py: ownship start drawn like an intruder."""
+    _variant = "random_start"

@@ -201,6 +201,13 @@ static double dist_own_intruder(const env_t* e, const intruder_t* it)
     return sqrt(fma(dy, dy, dx * dx));
 }
 
+/* `dist < threshold` as NumPy evaluates it: a float32 distance against a Python float compares in
+ * float32 (NEP 50 weak scalar); a float64 distance compares in float64. */
+static int dist_lt(const intruder_t* it, double d, double thr)
+{
+    return it->promoted ? (d < thr) : ((float)d < (float)thr);
+}
+
 /* dist(drone, goal): float32 - float64 -> float64, :179,:185 */
 static double dist_own_goal(const env_t* e)
 {
@@ -242,7 +249,7 @@ static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t*
     out->conflict = 0;
     e->spawns++;
     uint32_t attempt = 0;
-    while (dist_own_intruder(e, out) < g->initial_min_dist) {   /* :85-86, :236-237 */
+    while (dist_lt(out, dist_own_intruder(e, out), g->initial_min_dist)) {   /* :85-86, :236-237 */
         attempt++;
         if (g->rng_mode == UAM_RNG_MT19937) {
             px = 0.0 + g->window_width * mt_double(e->mt);
@@ -404,15 +411,16 @@ static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info
         double d = dist_own_intruder(e, it);
         old = *it;
         /* position_range.contains: inclusive bounds, :151 */
-        int inside = (it->x >= 0.0) && (it->y >= 0.0) && (it->x <= g->window_width) && (it->y <= g->window_height);
+        int inside = (it->x >= 0.0) && (it->y >= 0.0) && (it->x <= (double)(float)g->window_width) &&
+                     (it->y <= (double)(float)g->window_height);   /* Box low/high are float32 arrays */
         if (!inside) spawn_intruder(c, idx, 0, it);   /* :152, new object: conflict flag cleared */
-        if (d < g->minimum_separation) {              /* :155 */
+        if (dist_lt(&old, d, g->minimum_separation)) {   /* :155 */
             conflict = 1;
             if (!old.conflict) {                      /* the OLD object's flag, :159-161 */
                 e->no_conflict += 1;
                 if (inside) it->conflict = 1;         /* flag set on the old object; lost if it was replaced */
             }
-            if (d < g->nmac_dist) {                   /* :167-168 early exit */
+            if (dist_lt(&old, d, g->nmac_dist)) {        /* :167-168 early exit */
                 *reward = g->nmac_penalty; *done = 1; *info = UAM_INFO_NMAC;
                 return;
             }

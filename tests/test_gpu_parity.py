@@ -1,0 +1,255 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs, against the committed reference-generated golden fixtures, and — at BASELINE.json's full
+sizes — through size-independent properties.
+
+Bars (north_star): discrete collision/done/info flags bit-exact; float32 state bit-exact against the
+oracle built with the same portable math; rewards bit-exact as float32; observations within 1e-6
+(the float32 pack rounds the reference's float64 tail entries).  Against the reference's own
+trajectories (golden fixtures, libm trig): flags exact, floats within 1e-5 abs (north_star's bound).
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uamenv():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import uamenv as m
+    m._capi.lib()   # raises if the HIP extension is missing: no fallback
+    return m
+
+
+# ---------------------------------------------------------------- Philox (throughput mode) vs oracle
+@pytest.mark.parametrize("B,N,T,policy", [
+    (256, 4, 300, "goal"),      # L=1: one lane per env
+    (512, 8, 400, "mixed"),     # BASELINE config 2 shape (smaller batch)
+    (384, 32, 400, "goal"),     # BASELINE config 3 shape: 8 lanes per env
+    (96, 80, 250, "goal"),      # shipped Config.intruder_size: 20 of 32 lanes active
+    (200, 5, 200, "goal"),      # N not a multiple of 4: padded quad, scalar obs stores
+    (64, 20, 200, "mixed"),     # MCTS config N
+    (33, 256, 60, "goal"),      # one full wave per env
+    (4096, 8, 64, "random"),    # BASELINE config 2 at full batch
+])
+def test_philox_f32_matches_oracle(uamenv, oracle, B, N, T, policy):
+    out = pu.run_lockstep(uamenv, oracle, B, N, T, policy=policy, rng="philox", precision="f32",
+                          check_state_every=10)
+    if policy != "random" and B * T >= 10000:
+        assert out["counts"][1] > 0, "no conflict step exercised: %s" % out["counts"]
+        assert out["spawns"] > B * N, "no respawn exercised"
+
+
+@pytest.mark.parametrize("B,N,T", [(256, 8, 300), (128, 32, 300), (64, 80, 150)])
+def test_philox_exact_promotion_matches_oracle(uamenv, oracle, B, N, T):
+    """float64 'promoted' positions after a rejection redraw (SingleAircraftEnv.py:85-86,236-237)."""
+    out = pu.run_lockstep(uamenv, oracle, B, N, T, policy="goal", rng="philox", precision="exact",
+                          check_state_every=10)
+    assert out["redraws"] > 0, "no promotion exercised"
+
+
+@pytest.mark.parametrize("variant,N", [("continuous", 8), ("mcts", 8), ("randintruder", 8), ("randintruder", 64),
+                                       ("random_start", 8)])
+@pytest.mark.parametrize("precision", ["f32", "exact"])
+def test_variants_match_oracle(uamenv, oracle, variant, N, precision):
+    pu.run_lockstep(uamenv, oracle, 192, N, 200, policy="goal", variant=variant, rng="philox", precision=precision,
+                    check_state_every=10)
+
+
+def test_sparse_reward_and_no_auto_reset(uamenv, oracle):
+    class Cfg(uamenv.Config):
+        sparse_reward = True
+    pu.run_lockstep(uamenv, oracle, 128, 8, 120, policy="goal", rng="philox", precision="f32", config=Cfg,
+                    auto_reset=False, check_state_every=10)
+
+
+# ---------------------------------------------------------------- MT19937 (NumPy stream) vs oracle
+@pytest.mark.parametrize("variant,N,T", [("discrete9", 8, 400), ("discrete9", 32, 300), ("randintruder", 8, 200),
+                                         ("continuous", 8, 150)])
+def test_mt19937_matches_oracle(uamenv, oracle, variant, N, T):
+    """One NumPy-legacy stream per env, consumed in the reference's draw order; oracle built with the same
+    portable math, so even the float state must match to the bit."""
+    pu.run_lockstep(uamenv, oracle, 96, N, T, policy="goal", variant=variant, rng="mt19937", precision="exact",
+                    check_state_every=10)
+
+
+# ---------------------------------------------------------------- against the reference's own trajectories
+VARIANT_OF = {(0, 0, 0): "discrete9", (0, 2, 0): "continuous", (1, 1, 0): "mcts", (2, 1, 1): "randintruder"}
+
+
+@pytest.mark.parametrize("name", gu.TRAJECTORY_FIXTURES)
+def test_gpu_replays_reference_fixture_from_seed(uamenv, name):
+    """The HIP env, seeded like np.random.seed(s), replays what the REFERENCE produced: flags/counters
+    bit-exact, floats within north_star's 1e-5 (device trig/log differ from glibc by <= 1 ulp)."""
+    fx = gu.load(name)
+    N = int(fx["meta_N"])
+    variant = VARIANT_OF[(int(fx["meta_obs_mode"]), int(fx["meta_action_mode"]), int(fx["meta_dynamics"]))]
+    over = {k: float(fx["meta_" + k]) for k in ("heading_sigma", "speed_sigma") if "meta_" + k in fx}
+    env = uamenv.BatchedSingleAircraftEnv(1, N, variant=variant, rng="mt19937", precision="exact",
+                                          seed=int(fx["meta_seed"]), auto_reset=False, **over)
+    raw = int(fx["meta_obs_mode"]) != 0
+    tol = 1e-5
+
+    def close(a, b, what):
+        d = np.abs(a.astype(np.float64) - b)
+        lim = tol * (np.maximum(1.0, np.abs(b)) if raw else 1.0)   # raw obs carry positions up to 800 (fp32 ulp 6e-5)
+        assert (d <= lim).all(), "%s: max |d| = %g" % (what, d.max())
+
+    close(env.reset().cpu().numpy()[0], fx["obs0"], name + " reset obs")
+    inj = gu.prefixed_state(fx, "inj_")
+    if inj:
+        hold = {"int_speed", "int_heading"}
+        env.set_state({k: v for k, v in inj.items() if k not in hold})
+    reset_steps = {int(t): i for i, t in enumerate(fx["reset_steps"])}
+    actions = fx["actions"]
+    for t in range(len(actions)):
+        obs, rew, done, infos = env.step(actions[t:t + 1])
+        where = "%s step %d" % (name, t)
+        assert bool(done[0].item()) == bool(fx["done"][t]), where + ": done"
+        assert int(infos.codes[0].item()) == int(fx["info"][t]), where + ": info"
+        assert abs(float(rew[0].item()) - fx["reward"][t]) <= tol, where + ": reward"
+        close(obs.cpu().numpy()[0], fx["obs"][t], where + " obs")
+        assert int(env.no_conflict[0].item()) == int(fx["no_conflict"][t]), where + ": no_conflict"
+        if fx["done"][t]:
+            close(env.reset().cpu().numpy()[0], fx["reset_obs"][reset_steps[t]], where + " reset obs")
+        if t % 16 == 0 or fx["done"][t]:
+            st = env.get_state(["int_conflict", "int_promoted"])
+            assert np.array_equal(st["int_conflict"][0], fx["conflict"][t]), where + ": conflict flags"
+            assert np.array_equal(st["int_promoted"][0], fx["promoted"][t]), where + ": promoted flags"
+    env.close()
+
+
+def test_gym_style_env_is_a_drop_in(uamenv):
+    """gym.Env duck type: signatures, types and info dict of Simulators/SingleAircraftEnv.py:64,126-139."""
+    fx = gu.load("g1_discrete9_n4_seed0")
+    env = uamenv.SingleAircraftEnv(num_intruders=4)
+    assert env.seed(0) == [0]
+    obs = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float64 and obs.shape == (24,)
+    assert env.observation_space.shape == (24,) and env.action_space.n == 9 and env.intruder_size == 4
+    assert np.abs(obs - fx["obs0"]).max() <= 1e-5
+    for t in range(64):
+        obs, reward, done, info = env.step(int(fx["actions"][t]))
+        assert isinstance(reward, float) and isinstance(done, bool) and set(info) == {"result"}
+        assert np.abs(obs - fx["obs"][t]).max() <= 1e-5 and abs(reward - fx["reward"][t]) <= 1e-5
+        assert info["result"] == ["", "c", "g", "n"][fx["info"][t]] and done == bool(fx["done"][t])
+    assert env.no_conflict == int(fx["no_conflict"][63])
+    assert env.render() is None
+    env.close()
+    ri = uamenv.SingleAircraftMCTSRandIntruderEnv(num_intruders=8)
+    ri.seed(13)
+    o = ri.reset()
+    assert o.shape == (6 * 8 + 8,)
+    o, r, d, info = ri.step((1, 2))
+    assert isinstance(info, str)
+    ri.close()
+
+
+# ---------------------------------------------------------------- API behaviour
+def test_reset_mask_state_roundtrip_and_step_many(uamenv, oracle):
+    import torch
+    B, N = 64, 8
+    env = uamenv.BatchedSingleAircraftEnv(B, N, seed=5)
+    env.reset()
+    st0 = env.get_state()
+    # masked reset touches only the masked envs
+    mask = np.zeros(B, np.uint8)
+    mask[::3] = 1
+    before = env.observe().clone()
+    after = env.reset(mask).clone()
+    same = (before == after).all(dim=1).cpu().numpy()
+    assert same[mask == 0].all() and not same[mask == 1].any()
+    # set_state(get_state()) is the identity and the continuation is deterministic
+    env.set_state(st0)
+    tape = torch.randint(0, 9, (20, B), dtype=torch.int32, device=env.device)
+    _, r1, d1, i1 = env.step_many(tape)
+    o1 = env.observe().clone()
+    env.set_state(st0)
+    rs, ds = [], []
+    for k in range(20):
+        o, r, d, _ = env.step(tape[k])
+        rs.append(r.clone())
+        ds.append(d.clone())
+    assert torch.equal(torch.stack(rs), r1) and torch.equal(torch.stack(ds).to(torch.uint8), d1)
+    assert torch.equal(env.observe(), o1)
+    env.close()
+
+
+def test_bad_arguments_fail_loudly(uamenv):
+    with pytest.raises(uamenv.UamError):
+        uamenv.BatchedSingleAircraftEnv(8, 300)          # N > 256
+    with pytest.raises(uamenv.UamError):
+        uamenv.BatchedSingleAircraftEnv(0, 8)
+    env = uamenv.BatchedSingleAircraftEnv(8, 8)
+    with pytest.raises(ValueError):
+        env.step(np.zeros(7, np.int32))
+    with pytest.raises(uamenv.UamError):
+        env.set_state({"int_promoted": np.ones((8, 8), np.uint8)})   # needs precision='exact'
+    env.close()
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE config 3)
+def test_full_size_matches_threaded_oracle_and_is_shard_invariant(uamenv, oracle):
+    """B=65536 x N=32 (the roofline configuration): a few steps against the 8-thread oracle, bit-exact
+    checksums; then the same batch split over two handles by env_id_offset must give identical results
+    (what the multi-GPU sharding relies on)."""
+    import torch
+    B, N, T = 65536, 32, 12
+    env = uamenv.BatchedSingleAircraftEnv(B, N, seed=2024)
+    ocfg = pu.oracle_cfg_from(oracle, env.cfg)
+    orc = oracle.OracleBatch(ocfg, oracle.MATH_PORTABLE, threads=16)
+    env.reset()
+    orc.reset(want_obs=False)
+    halves = [uamenv.BatchedSingleAircraftEnv(B // 2, N, seed=2024, env_id_offset=k * (B // 2)) for k in range(2)]
+    for h in halves:
+        h.reset()
+    ost = orc.get_state()
+    for t in range(T):
+        acts = pu.goal_seek_actions(ost, env.cfg.d_heading, 0)
+        o, r, d, inf = env.step(acts)
+        oo = orc.step(acts, want_obs=False)
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), oo[2]) and np.array_equal(inf.codes.cpu().numpy(), oo[3])
+        assert np.array_equal(r.cpu().numpy(), oo[1].astype(np.float32))
+        ost = orc.get_state()
+        for k, h in enumerate(halves):
+            sl = slice(k * (B // 2), (k + 1) * (B // 2))
+            ho, hr, hd, _ = h.step(acts[sl])
+            assert torch.equal(ho, o[sl]) and torch.equal(hr, r[sl]) and torch.equal(hd, d[sl])
+    pu.compare_states(env.get_state(), ost, "full size, after %d steps" % T)
+    env.close()
+    for h in halves:
+        h.close()
+
+
+def test_full_size_invariants_under_random_policy(uamenv):
+    """Properties that need no oracle: determinism, bounds, flag/reward consistency, auto-reset."""
+    import torch
+    B, N, T = 65536, 32, 200
+    runs = []
+    for rep in range(2):
+        env = uamenv.BatchedSingleAircraftEnv(B, N, seed=99)
+        env.reset()
+        acc = torch.zeros(4, dtype=torch.float64, device=env.device)
+        for t in range(T):
+            a = env.policy_actions("goal" if t % 2 else "random", seed=3)
+            obs, rew, done, infos = env.step(a)
+            codes = infos.codes
+            # reward <-> info <-> done consistency (SingleAircraftEnv.py:167-185)
+            assert bool(((codes == 3) == (rew == -1.0)).all()) and bool(((codes == 1) == (rew == -0.5)).all())
+            assert bool((done == ((codes == 2) | (codes == 3))).all())
+            assert bool((rew[codes == 0] <= 0).all()) and bool((rew[codes == 2] == 1.0).all())
+            # normalised intruder positions stay inside the map (respawn on leaving it)
+            pos = obs[:, :4 * N].reshape(B, N, 4)[:, :, :2]
+            assert bool(((pos >= 0) & (pos <= 1)).all())
+            # a done env was auto-reset: ownship back at (50,50)/800
+            if bool(done.any()):
+                assert bool((obs[done][:, 4 * N:4 * N + 2] == 0.0625).all())
+            acc += torch.stack([rew.double().sum(), done.double().sum(), codes.double().sum(), obs.double().sum()])
+        runs.append(acc.cpu().numpy())
+        env.close()
+    assert np.array_equal(runs[0], runs[1]), "two runs from the same seed differ: %s vs %s" % (runs[0], runs[1])
+    assert runs[0][1] > 0, "no episode ended in %d steps" % T
