@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libuamenv_hip.so")
+LIB_PATH = os.environ.get("UAMENV_LIB") or os.path.join(CSRC, "libuamenv_hip.so")   # UAMENV_LIB: development override
 
 OBS_NORM4, OBS_RAW4, OBS_RAW6 = 0, 1, 2
 ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1 = 0, 1, 2
@@ -58,8 +58,9 @@ class UamStateView(C.Structure):
         ("own_x", C.c_void_p), ("own_y", C.c_void_p),
         ("own_heading", C.c_void_p), ("own_speed", C.c_void_p), ("own_vx", C.c_void_p), ("own_vy", C.c_void_p),
         ("goal_x", C.c_void_p), ("goal_y", C.c_void_p),
-        ("no_conflict", C.c_void_p), ("step_count", C.c_void_p),
+        ("no_conflict", C.c_void_p), ("reset_count", C.c_void_p),
         ("mt_key", C.c_void_p), ("mt_pos", C.c_void_p), ("mt_has_gauss", C.c_void_p), ("mt_gauss", C.c_void_p),
+        ("step_index", C.c_uint64),
     ]
 
 
@@ -72,7 +73,7 @@ STATE_FIELDS = {
     "own_heading": (np.float64, "B"), "own_speed": (np.float64, "B"),
     "own_vx": (np.float64, "B"), "own_vy": (np.float64, "B"),
     "goal_x": (np.float64, "B"), "goal_y": (np.float64, "B"),
-    "no_conflict": (np.int32, "B"), "step_count": (np.uint32, "B"),
+    "no_conflict": (np.int32, "B"), "reset_count": (np.uint32, "B"),
     "mt_key": (np.uint32, "B624"), "mt_pos": (np.int32, "B"),
     "mt_has_gauss": (np.int32, "B"), "mt_gauss": (np.float64, "B"),
 }
@@ -154,7 +155,11 @@ def make_view(arrays, B, N):
     v = UamStateView()
     v.struct_size = C.sizeof(UamStateView)
     v.num_envs, v.num_intruders = B, N
+    v.step_index = 0xFFFFFFFFFFFFFFFF   # uam_set_state: keep the handle's step index unless given
     for name, arr in arrays.items():
+        if name == "step_index":
+            v.step_index = int(arr)
+            continue
         if name not in STATE_FIELDS:
             raise KeyError(name)
         dt, shape = STATE_FIELDS[name]

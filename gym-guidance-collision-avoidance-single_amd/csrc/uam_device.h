@@ -33,9 +33,17 @@
 #include "../../include/uamenv.h"
 #include "uam_pmath.h"
 
+#ifndef UAM_ABLATE
+#define UAM_ABLATE 0   /* development-only ablation mask (tools/ablate.py); 0 in every shipped build */
+#endif
 #define UAM_MT_N 624
 #define UAM_MT_M 397
 #define UAM_MAX_BLOCK 512
+#ifndef UAM_STEP_WAVES_PER_EU
+#define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK)
+#else
+#define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_STEP_WAVES_PER_EU, 8)))
+#endif
 
 /* device pointers of the struct-of-arrays env state (HBM) */
 struct UamDev {
@@ -55,7 +63,7 @@ struct UamDev {
     double*  goal_x;
     double*  goal_y;
     int32_t* no_conflict;
-    uint32_t* step_count;
+    uint32_t* reset_count; /* [B] episodes started so far: Philox counter of the reset draws */
     uint32_t* mt_key;   /* [B*624] */
     int32_t* mt_pos;    /* [B] next word to consume (624 = wrap first) */
     int32_t* mt_gen;    /* [B] words [0,gen) of the current round are already twisted */
@@ -72,6 +80,9 @@ struct UamParams {
         heading_sigma, nmac_pen, conf_pen, step_pen, goal_rew, dense_div, own_x0, own_y0, own_speed0,
         own_heading0, hc_prob, hc_max_deg;
     float W32, H32, vmax32, vden32, psig32, min_sep32, nmac32, init_min32;
+    double inv_2vmax, inv_vrange, inv_W, inv_H;   /* reciprocals for the float32 obs tail (tolerance, not parity) */
+    uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
+    const double2* noise;         /* [B] (zh, zs) of this step, produced ahead by uam_noise_kernel (Philox) */
     /* per-call I/O (device pointers owned by the caller) */
     const void* actions;
     float* obs;
@@ -89,13 +100,13 @@ struct EnvShare {
     float own_x, own_y;
     float rew_tail;      /* reward if neither NMAC nor conflict: goal reward or dense/sparse step reward */
     uint32_t goal_hit;
-    uint32_t ctr;        /* step counter used for this step's Philox draws */
-    uint32_t pad[3];
+    uint32_t pad[4];
     float tail[8];       /* ownship(6) + goal(2) part of the observation */
 };
 
-enum { UAM_PH_OWN_NOISE = 0, UAM_PH_SPAWN_POS = 1, UAM_PH_SPAWN_SH = 2, UAM_PH_RESET_POS = 3, UAM_PH_RESET_SH = 4,
-       UAM_PH_RESET_GOAL = 5, UAM_PH_HEADCHG = 6, UAM_PH_POLICY = 7, UAM_PH_RESET_OWN = 8 };
+/* Philox counter = (global env id, step_index | reset_count, purpose << 16 | idx, attempt) */
+enum { UAM_PH_OWN_NOISE = 0, UAM_PH_SPAWN = 1, UAM_PH_RESET_SPAWN = 3, UAM_PH_RESET_GOAL = 5, UAM_PH_HEADCHG = 6,
+       UAM_PH_POLICY = 7, UAM_PH_RESET_OWN = 8 };
 
 #define UAM_TWO_PI 0x1.921fb54442d18p+2
 #define UAM_DEG2RAD (0x1.921fb54442d18p+1 / 180.0)
@@ -120,6 +131,7 @@ __device__ __forceinline__ double uam_u53(uint32_t a, uint32_t b)
 {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
 }
+__device__ __forceinline__ double uam_u32d(uint32_t a) { return (double)a * 0x1p-32; }
 __device__ __forceinline__ double uam_u53_open0(uint32_t a, uint32_t b)
 {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 1.0) * 0x1p-53;
@@ -202,61 +214,65 @@ __device__ inline double mt_gauss(MtCtx& m)
     return f * x2;
 }
 
-/* ------------------------------------------------------------------ RNG adaptors */
+/* ------------------------------------------------------------------ RNG adaptors
+ * quad(): the four uniforms of one spawn (x, y, speed, heading); two(): a redraw / the goal.
+ * Philox draws one 4x32 block per call (32 random bits per quantity); MT19937 consumes the
+ * env's NumPy stream in the reference's order (53-bit rk_double each). */
 template <int RNG> struct Rng;
 
 template <> struct Rng<UAM_RNG_PHILOX> {
-    uint32_t gid, ctr, k0, k1;
+    uint32_t gid, c_step, c_reset, k0, k1;
     __device__ __forceinline__ void load(const UamDev&, int) {}
     __device__ __forceinline__ void store(const UamDev&, int) {}
-    __device__ __forceinline__ void pair(uint32_t purpose, uint32_t idx, uint32_t attempt, double& u1, double& u2)
+    __device__ __forceinline__ void block(bool reset_phase, uint32_t purpose, uint32_t idx, uint32_t attempt, uint32_t* w)
+    {
+        uam_philox(gid, reset_phase ? c_reset : c_step, (purpose << 16) | idx, attempt, k0, k1, w);
+    }
+    __device__ __forceinline__ void quad(bool reset_phase, uint32_t purpose, uint32_t idx, double* u)
     {
         uint32_t w[4];
-        uam_philox(gid, ctr, (purpose << 16) | idx, attempt, k0, k1, w);
-        u1 = uam_u53(w[0], w[1]);
-        u2 = uam_u53(w[2], w[3]);
+        block(reset_phase, purpose, idx, 0, w);
+        u[0] = uam_u32d(w[0]); u[1] = uam_u32d(w[1]); u[2] = uam_u32d(w[2]); u[3] = uam_u32d(w[3]);
     }
-    __device__ __forceinline__ void normals(double& zh, double& zs)
+    __device__ __forceinline__ void two(bool reset_phase, uint32_t purpose, uint32_t idx, uint32_t attempt, double& u1,
+                                        double& u2)
     {
         uint32_t w[4];
-        uam_philox(gid, ctr, (UAM_PH_OWN_NOISE << 16), 0, k0, k1, w);
-        double u1 = uam_u53_open0(w[0], w[1]), u2 = uam_u53(w[2], w[3]);
-        double r = __builtin_sqrt(-2.0 * uam_log(u1));
-        double sn, cs;
-        uam_sincos(UAM_TWO_PI * u2, &sn, &cs);
-        zh = r * cs;
-        zs = r * sn;
-    }
-    __device__ __forceinline__ void headchg(uint32_t idx, double prob, bool& take, double& ud)
-    {
-        double p;
-        pair(UAM_PH_HEADCHG, idx, 0, p, ud);
-        take = p < prob;
+        block(reset_phase, purpose, idx, attempt, w);
+        u1 = uam_u32d(w[0]);
+        u2 = uam_u32d(w[1]);
     }
 };
 
 template <> struct Rng<UAM_RNG_MT19937> {
     MtCtx m;
-    uint32_t gid, ctr, k0, k1; /* unused */
+    uint32_t gid, c_step, c_reset, k0, k1; /* unused */
     __device__ __forceinline__ void load(const UamDev& s, int e) { mt_load(s, e, m); }
     __device__ __forceinline__ void store(const UamDev& s, int e) { mt_store(s, e, m); }
-    __device__ __forceinline__ void pair(uint32_t, uint32_t, uint32_t, double& u1, double& u2)
+    __device__ __forceinline__ void quad(bool, uint32_t, uint32_t, double* u)
+    {
+        u[0] = mt_double(m); u[1] = mt_double(m); u[2] = mt_double(m); u[3] = mt_double(m);
+    }
+    __device__ __forceinline__ void two(bool, uint32_t, uint32_t, uint32_t, double& u1, double& u2)
     {
         u1 = mt_double(m);
         u2 = mt_double(m);
     }
-    __device__ __forceinline__ void normals(double& zh, double& zs)
-    {
-        zh = mt_gauss(m);
-        zs = mt_gauss(m);
-    }
-    __device__ __forceinline__ void headchg(uint32_t, double prob, bool& take, double& ud)
-    {
-        double p = 0.0 + 1.0 * mt_double(m);
-        take = p < prob;
-        ud = take ? mt_double(m) : 0.0;
-    }
 };
+
+/* Box-Muller pair for the ownship noise of (env gid, step c_step): heading noise zh, speed noise zs */
+__device__ __forceinline__ void uam_philox_normals(uint32_t gid, uint32_t c_step, uint32_t k0, uint32_t k1, double& zh,
+                                                   double& zs)
+{
+    uint32_t w[4];
+    uam_philox(gid, c_step, (UAM_PH_OWN_NOISE << 16), 0, k0, k1, w);
+    const double u1 = uam_u53_open0(w[0], w[1]), u2 = uam_u53(w[2], w[3]);
+    const double r = __builtin_sqrt(-2.0 * uam_log(u1));
+    double sn, cs;
+    uam_sincos(UAM_TWO_PI * u2, &sn, &cs);
+    zh = r * cs;
+    zs = r * sn;
+}
 
 /* ------------------------------------------------------------------ small helpers */
 template <bool POS64> struct PosT { typedef float type; };
@@ -312,14 +328,12 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
                                       bool& prom, float& vx, float& vy, double& sp, double& hd)
 {
     typedef typename PosT<POS64>::type P;
-    const uint32_t ppos = reset_phase ? UAM_PH_RESET_POS : UAM_PH_SPAWN_POS;
-    const uint32_t psh = reset_phase ? UAM_PH_RESET_SH : UAM_PH_SPAWN_SH;
-    double u1, u2, u3, u4;
-    rng.pair(ppos, idx, 0, u1, u2);
-    rng.pair(psh, idx, 0, u3, u4);
-    double fx = 0.0 + p.W * u1, fy = 0.0 + p.H * u2;
-    sp = p.min_speed + (p.max_speed - p.min_speed) * u3;
-    hd = 0.0 + (UAM_TWO_PI - 0.0) * u4;
+    const uint32_t purpose = reset_phase ? UAM_PH_RESET_SPAWN : UAM_PH_SPAWN;
+    double u[4];
+    rng.quad(reset_phase, purpose, idx, u);
+    double fx = 0.0 + p.W * u[0], fy = 0.0 + p.H * u[1];
+    sp = p.min_speed + (p.max_speed - p.min_speed) * u[2];
+    hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
     double sn, cs;
     uam_sincos(hd, &sn, &cs);
     vx = (float)(sp * cs);
@@ -330,7 +344,8 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
     uint32_t attempt = 0;
     while (too_close<POS64>(ox, oy, X, Y, prom, p)) {
         attempt++;
-        rng.pair(ppos, idx, attempt, u1, u2);
+        double u1, u2;
+        rng.two(reset_phase, purpose, idx, attempt, u1, u2);
         fx = 0.0 + p.W * u1;
         fy = 0.0 + p.H * u2;
         if (POS64) { X = (P)fx; Y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
@@ -338,20 +353,34 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
     }
 }
 
-/* registers of one lane's quad */
-template <bool POS64> struct Quad {
+/* registers of one lane's quad (SH: intruder speed/heading are held) */
+template <bool POS64, bool SH> struct Quad {
     typename PosT<POS64>::type x[4], y[4];
     float vx[4], vy[4];
-    double sp[4], hd[4];
+    double sp[SH ? 4 : 1], hd[SH ? 4 : 1];
     uint32_t flags; /* low nibble conflict, high nibble promoted */
+    __device__ __forceinline__ void set(int j, typename PosT<POS64>::type X, typename PosT<POS64>::type Y, bool prom,
+                                        float vx_, float vy_, double sp_, double hd_)
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k == j) {
+                x[k] = X; y[k] = Y; vx[k] = vx_; vy[k] = vy_;
+                if (SH) { sp[k] = sp_; hd[k] = hd_; }
+                flags &= ~((1u << k) | (1u << (4 + k)));   /* new object: conflict flag cleared */
+                flags |= (prom ? 1u : 0u) << (4 + k);
+            }
+    }
 };
 
-template <bool POS64>
-__device__ __forceinline__ void quad_load(const UamParams& p, size_t base, bool ok, bool with_sh, Quad<POS64>& q)
+template <bool POS64, bool SH>
+__device__ __forceinline__ void quad_load(const UamParams& p, size_t base, bool ok, Quad<POS64, SH>& q)
 {
     typedef typename PosT<POS64>::type P;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { q.x[j] = (P)0; q.y[j] = (P)0; q.vx[j] = 0.f; q.vy[j] = 0.f; q.sp[j] = 0.0; q.hd[j] = 0.0; }
+    for (int j = 0; j < 4; j++) { q.x[j] = (P)0; q.y[j] = (P)0; q.vx[j] = 0.f; q.vy[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < (SH ? 4 : 1); j++) { q.sp[j] = 0.0; q.hd[j] = 0.0; }
     q.flags = 0;
     if (!ok) return;
     if (POS64) {
@@ -371,17 +400,17 @@ __device__ __forceinline__ void quad_load(const UamParams& p, size_t base, bool 
     q.vx[0] = c.x; q.vx[1] = c.y; q.vx[2] = c.z; q.vx[3] = c.w;
     q.vy[0] = d.x; q.vy[1] = d.y; q.vy[2] = d.z; q.vy[3] = d.w;
     q.flags = p.s.qf[base >> 2];
-    if (with_sh) {
+    if (SH) {
         const double2* as = (const double2*)(p.s.isp + base);
         const double2* ah = (const double2*)(p.s.ihd + base);
         double2 s0 = as[0], s1 = as[1], h0 = ah[0], h1 = ah[1];
-        q.sp[0] = s0.x; q.sp[1] = s0.y; q.sp[2] = s1.x; q.sp[3] = s1.y;
-        q.hd[0] = h0.x; q.hd[1] = h0.y; q.hd[2] = h1.x; q.hd[3] = h1.y;
+        q.sp[0] = s0.x; q.sp[1] = s0.y; q.sp[SH ? 2 : 0] = s1.x; q.sp[SH ? 3 : 0] = s1.y;
+        q.hd[0] = h0.x; q.hd[1] = h0.y; q.hd[SH ? 2 : 0] = h1.x; q.hd[SH ? 3 : 0] = h1.y;
     }
 }
 
-template <bool POS64>
-__device__ __forceinline__ void quad_store_pos(const UamParams& p, size_t base, const Quad<POS64>& q)
+template <bool POS64, bool SH>
+__device__ __forceinline__ void quad_store_pos(const UamParams& p, size_t base, const Quad<POS64, SH>& q)
 {
     if (POS64) {
         double2* ax = (double2*)((double*)p.s.px + base);
@@ -396,25 +425,26 @@ __device__ __forceinline__ void quad_store_pos(const UamParams& p, size_t base, 
     }
 }
 
-template <bool POS64>
-__device__ __forceinline__ void quad_store_vel(const UamParams& p, size_t base, bool with_sh, const Quad<POS64>& q)
+template <bool POS64, bool SH>
+__device__ __forceinline__ void quad_store_vel(const UamParams& p, size_t base, const Quad<POS64, SH>& q)
 {
     *(float4*)(p.s.vx + base) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
     *(float4*)(p.s.vy + base) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
-    if (with_sh) {
+    if (SH) {
         double2* as = (double2*)(p.s.isp + base);
         double2* ah = (double2*)(p.s.ihd + base);
-        as[0] = make_double2(q.sp[0], q.sp[1]); as[1] = make_double2(q.sp[2], q.sp[3]);
-        ah[0] = make_double2(q.hd[0], q.hd[1]); ah[1] = make_double2(q.hd[2], q.hd[3]);
+        as[0] = make_double2(q.sp[0], q.sp[1]); as[1] = make_double2(q.sp[SH ? 2 : 0], q.sp[SH ? 3 : 0]);
+        ah[0] = make_double2(q.hd[0], q.hd[1]); ah[1] = make_double2(q.hd[SH ? 2 : 0], q.hd[SH ? 3 : 0]);
     }
 }
 
 /* _get_ob intruder part: SingleAircraftEnv.py:107-112 (NORM4), MCTSEnv.py:107-112 (RAW4),
- * RandIntruderEnv.py:133-140 (RAW6).  One lane writes its quad's 4*obs_w floats. */
-template <bool POS64>
-__device__ __forceinline__ void quad_obs(const UamParams& p, float* row, int q4, int nvalid, const Quad<POS64>& q)
+ * RandIntruderEnv.py:133-140 (RAW6).  One lane writes its quad's 4*obs_w floats to `dst`
+ * (an LDS staging row or, on the unaligned fallback, the global row). */
+template <bool POS64, bool SH>
+__device__ __forceinline__ void quad_obs(const UamParams& p, float* dst, bool vec, int nvalid, const Quad<POS64, SH>& q)
 {
-    float v[4][6];
+    float v[4][SH ? 6 : 4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
@@ -428,59 +458,61 @@ __device__ __forceinline__ void quad_obs(const UamParams& p, float* row, int q4,
             }
             v[j][2] = (q.vx[j] + p.vmax32) / p.vden32;
             v[j][3] = (q.vy[j] + p.vmax32) / p.vden32;
-            v[j][4] = 0.f; v[j][5] = 0.f;
         } else {
             v[j][0] = (float)q.x[j]; v[j][1] = (float)q.y[j];
             v[j][2] = q.vx[j];       v[j][3] = q.vy[j];
-            v[j][4] = (float)q.sp[j]; v[j][5] = (float)q.hd[j];
         }
+        if (SH) { v[j][SH ? 4 : 0] = (float)q.sp[j]; v[j][SH ? 5 : 0] = (float)q.hd[j]; }
     }
     const int w = p.obs_w;
-    float* dst = row + (size_t)q4 * w;
-    if (p.obs_vec && nvalid == 4) {
-        if (w == 4) {
+    if (vec && nvalid == 4) {
+        if (!SH || w == 4) {
 #pragma unroll
             for (int j = 0; j < 4; j++) ((float4*)dst)[j] = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
         } else {
+            const int a = SH ? 4 : 0, b = SH ? 5 : 0;
             ((float4*)dst)[0] = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-            ((float4*)dst)[1] = make_float4(v[0][4], v[0][5], v[1][0], v[1][1]);
-            ((float4*)dst)[2] = make_float4(v[1][2], v[1][3], v[1][4], v[1][5]);
+            ((float4*)dst)[1] = make_float4(v[0][a], v[0][b], v[1][0], v[1][1]);
+            ((float4*)dst)[2] = make_float4(v[1][2], v[1][3], v[1][a], v[1][b]);
             ((float4*)dst)[3] = make_float4(v[2][0], v[2][1], v[2][2], v[2][3]);
-            ((float4*)dst)[4] = make_float4(v[2][4], v[2][5], v[3][0], v[3][1]);
-            ((float4*)dst)[5] = make_float4(v[3][2], v[3][3], v[3][4], v[3][5]);
+            ((float4*)dst)[4] = make_float4(v[2][a], v[2][b], v[3][0], v[3][1]);
+            ((float4*)dst)[5] = make_float4(v[3][2], v[3][3], v[3][a], v[3][b]);
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (j < nvalid)
-                for (int k = 0; k < w; k++) dst[j * w + k] = v[j][k];
+#pragma unroll
+                for (int k = 0; k < (SH ? 6 : 4); k++)
+                    if (k < w) dst[j * w + k] = v[j][k];
     }
 }
 
-/* _get_ob ownship(6)+goal(2) part: SingleAircraftEnv.py:113-122 (NORM4) / MCTSEnv.py:113-122 (raw) */
+/* _get_ob ownship(6)+goal(2) part: SingleAircraftEnv.py:113-122 (NORM4) / MCTSEnv.py:113-122 (raw).
+ * float32 output: the float64 quotients are formed with reciprocals (within 1 ulp of the division
+ * before the float32 rounding; observations carry a tolerance, the state does not). */
 __device__ __forceinline__ void obs_tail(const UamParams& p, float ox, float oy, double vx, double vy, double sp,
                                          double hd, double gx, double gy, float* t)
 {
     if (p.obs_mode == UAM_OBS_NORM4) {
         t[0] = ox / p.W32;
         t[1] = oy / p.H32;
-        t[2] = (float)((vx + p.max_speed) / (p.max_speed * 2));
-        t[3] = (float)((vy + p.max_speed) / (p.max_speed * 2));
-        t[4] = (float)((sp - p.min_speed) / (p.max_speed - p.min_speed));
-        t[5] = (float)(hd / UAM_TWO_PI);
-        t[6] = (float)(gx / p.W);
-        t[7] = (float)(gy / p.H);
+        t[2] = (float)((vx + p.max_speed) * p.inv_2vmax);
+        t[3] = (float)((vy + p.max_speed) * p.inv_2vmax);
+        t[4] = (float)((sp - p.min_speed) * p.inv_vrange);
+        t[5] = (float)(hd * (1.0 / UAM_TWO_PI));
+        t[6] = (float)(gx * p.inv_W);
+        t[7] = (float)(gy * p.inv_H);
     } else {
         t[0] = ox; t[1] = oy; t[2] = (float)vx; t[3] = (float)vy;
         t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
     }
 }
 
-__device__ __forceinline__ void store_tail(const UamParams& p, float* row, int gl, const float* t)
+__device__ __forceinline__ void store_tail(const UamParams& p, float* dst, bool vec, int gl, const float* t)
 {
-    float* dst = row + (size_t)p.N * p.obs_w;
     const int second = p.L > 1 ? 1 : 0;
-    if (p.obs_vec) {
+    if (vec) {
         if (gl == 0) ((float4*)dst)[0] = make_float4(t[0], t[1], t[2], t[3]);
         if (gl == second) ((float4*)dst)[1] = make_float4(t[4], t[5], t[6], t[7]);
     } else if (gl == 0) {
@@ -488,69 +520,88 @@ __device__ __forceinline__ void store_tail(const UamParams& p, float* row, int g
     }
 }
 
+/* Observation pack of one wave.  Aligned case: every lane stages its piece of the rows in LDS in
+ * the final [env][D] layout, then the wave streams its contiguous span of rows to HBM with 16 B
+ * per lane (1 KiB per store instruction) — row-per-lane stores straight to HBM touch a different
+ * 128-B line per lane and are store-issue bound.  stage = this wave's LDS region. */
+template <bool POS64, bool SH>
+__device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, int env_first, int g_in_wave,
+                                              int gl, bool env_ok, bool quad_ok, const Quad<POS64, SH>& q,
+                                              const float* tail)
+{
+    const int lane = threadIdx.x & 63;
+    if (p.obs_vec) {
+        float* row = stage + (size_t)g_in_wave * p.D;
+        if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, true, min(4, p.N - 4 * gl), q);
+        if (env_ok) store_tail(p, row + (size_t)p.N * p.obs_w, true, gl, tail);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int envs_per_wave = 64 >> p.lshift;
+        const int nrows = min(envs_per_wave, p.B - env_first);
+        const int chunks = nrows * (p.D >> 2);
+        float4* gdst = (float4*)(p.obs + (size_t)env_first * p.D);
+        const float4* src = (const float4*)stage;
+        for (int c = lane; c < chunks; c += 64) gdst[c] = src[c];
+    } else if (env_ok) {
+        float* row = p.obs + (size_t)(env_first + g_in_wave) * p.D;
+        if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, false, min(4, p.N - 4 * gl), q);
+        store_tail(p, row + (size_t)p.N * p.obs_w, false, gl, tail);
+    }
+}
+
 /* SingleAircraftEnv.reset (:64-96) for one env, executed by its lane group.
  * Philox: lane-parallel (every lane spawns its own quad); MT19937: the draws are
  * sequential, so the group walks i = 0..N-1 uniformly and the owner lane keeps
- * the result.  ctr = Philox step counter to use; returns the env's new own/goal
- * state in the out params (group-uniform) and stores the per-env fields (lane 0). */
-template <bool POS64, int RNG>
-__device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, uint32_t ctr, Rng<RNG>& rng,
-                                 Quad<POS64>& q, float* tail)
+ * the result.  Stores the per-env fields (lane 0) and returns the obs tail. */
+template <bool POS64, int RNG, bool SH>
+__device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, Rng<RNG>& rng,
+                                 Quad<POS64, SH>& q, float* tail)
 {
-    rng.ctr = ctr;
+    const uint32_t rc = p.s.reset_count[env];
+    rng.c_reset = rc;
     double ox = p.own_x0, oy = p.own_y0, osp = p.own_speed0, ohd = p.own_heading0;
     if (p.random_own_start) {   /* SingleAircraftRandomEnv.py:70-74 */
-        double u1, u2, u3, u4;
-        rng.pair(UAM_PH_RESET_OWN, 0, 0, u1, u2);
-        rng.pair(UAM_PH_RESET_OWN, 1, 0, u3, u4);
-        ox = 0.0 + p.W * u1; oy = 0.0 + p.H * u2;
-        osp = p.min_speed + (p.max_speed - p.min_speed) * u3;
-        ohd = 0.0 + (UAM_TWO_PI - 0.0) * u4;
+        double u[4];
+        rng.quad(true, UAM_PH_RESET_OWN, 0, u);
+        ox = 0.0 + p.W * u[0]; oy = 0.0 + p.H * u[1];
+        osp = p.min_speed + (p.max_speed - p.min_speed) * u[2];
+        ohd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
     }
     const float oxf = (float)ox, oyf = (float)oy;
     double sn, cs;
     uam_sincos(ohd, &sn, &cs);
     const double ovx = (double)(float)(osp * cs), ovy = (double)(float)(osp * sn);
-    uint32_t flags = 0;
-    if (RNG == UAM_RNG_PHILOX) {
+    q.flags = 0;
+    if constexpr (RNG == UAM_RNG_PHILOX) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t idx = 4u * gl + j;
             if (quad_ok && idx < (uint32_t)p.N) {
-                bool prom;
-                spawn_intruder<POS64, RNG>(p, rng, idx, true, oxf, oyf, q.x[j], q.y[j], prom, q.vx[j], q.vy[j],
-                                           q.sp[j], q.hd[j]);
-                flags |= (prom ? 1u : 0u) << (4 + j);
+                typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
+                spawn_intruder<POS64, RNG>(p, rng, idx, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
+                q.set(j, X, Y, prom, vx, vy, sp, hd);
             }
         }
     } else {
         for (int i = 0; i < p.N; i++) {
-            typename PosT<POS64>::type X, Y;
-            bool prom;
-            float vx, vy;
-            double sp, hd;
+            typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
             spawn_intruder<POS64, RNG>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
-            if ((i >> 2) == gl) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((i & 3) == j) {
-                        q.x[j] = X; q.y[j] = Y; q.vx[j] = vx; q.vy[j] = vy; q.sp[j] = sp; q.hd[j] = hd;
-                        flags |= (prom ? 1u : 0u) << (4 + j);
-                    }
-            }
+            if ((i >> 2) == gl) q.set(i & 3, X, Y, prom, vx, vy, sp, hd);
         }
     }
-    q.flags = flags;
     double g1, g2;
-    rng.pair(UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
+    rng.two(true, UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
     const double gx = 0.0 + p.W * g1, gy = 0.0 + p.H * g2;
+    /* every lane of the group has read reset_count above; the group is one wave-resident unit */
+    __builtin_amdgcn_wave_barrier();
     if (gl == 0) {
         p.s.own_x[env] = oxf; p.s.own_y[env] = oyf;
         p.s.own_h[env] = ohd; p.s.own_s[env] = osp;
         p.s.own_vx[env] = ovx; p.s.own_vy[env] = ovy;
         p.s.goal_x[env] = gx; p.s.goal_y[env] = gy;
         p.s.no_conflict[env] = 0;
-        p.s.step_count[env] = ctr + 1u;
+        p.s.reset_count[env] = rc + 1u;
     }
     obs_tail(p, oxf, oyf, ovx, ovy, osp, ohd, gx, gy, tail);
 }
@@ -563,7 +614,6 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
     float ox = p.s.own_x[e], oy = p.s.own_y[e];
     double hd = p.s.own_h[e], sp = p.s.own_s[e];
     const double gx = p.s.goal_x[e], gy = p.s.goal_y[e];
-    const uint32_t ctr = p.s.step_count[e];
     double a0 = 1.0, a1 = 1.0;
     bool has_speed = true;
     if (p.action_mode == UAM_ACT_DISCRETE9) {
@@ -576,35 +626,31 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
         a0 = (double)((const float*)p.actions)[e];
         has_speed = false;
     }
-    Rng<RNG> rng;
-    rng.gid = p.gid0 + (uint32_t)e; rng.ctr = ctr; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
-    rng.load(p.s, e);
     double zh, zs;
-    if (RNG == UAM_RNG_PHILOX) {
-        rng.normals(zh, zs);
-        hd += p.d_heading * (a0 - 1.0);
-        hd += 0.0 + p.heading_sigma * zh;
-        if (has_speed) sp += p.d_speed * (a1 - 1.0);
-        sp = fmax(p.min_speed, fmin(sp, p.max_speed));
-        sp += 0.0 + p.speed_sigma * zs;
+    if constexpr (RNG == UAM_RNG_PHILOX) {
+        if (UAM_ABLATE & 1) { zh = 0.25; zs = -0.125; }
+        else { const double2 z = p.noise[e]; zh = z.x; zs = z.y; }   /* drawn ahead by uam_noise_kernel */
     } else {
-        rng.normals(zh, zs);   /* nothing else draws between the two normals */
-        hd += p.d_heading * (a0 - 1.0);
-        hd += 0.0 + p.heading_sigma * zh;
-        if (has_speed) sp += p.d_speed * (a1 - 1.0);
-        sp = fmax(p.min_speed, fmin(sp, p.max_speed));
-        sp += 0.0 + p.speed_sigma * zs;
+        Rng<UAM_RNG_MT19937> rng;
+        rng.load(p.s, e);
+        zh = mt_gauss(rng.m);   /* nothing else draws between the two normals */
+        zs = mt_gauss(rng.m);
         rng.store(p.s, e);
     }
+    hd += p.d_heading * (a0 - 1.0);
+    hd += 0.0 + p.heading_sigma * zh;
+    if (has_speed) sp += p.d_speed * (a1 - 1.0);
+    sp = fmax(p.min_speed, fmin(sp, p.max_speed));
+    sp += 0.0 + p.speed_sigma * zs;
     double sn, cs;
-    uam_sincos(hd, &sn, &cs);
+    if (UAM_ABLATE & 1) { sn = 0.6; cs = 0.8; }
+    else uam_sincos(hd, &sn, &cs);
     const double vx = sp * cs, vy = sp * sn;
     ox = (float)((double)ox + vx);      /* float32 position += float64 velocity */
     oy = (float)((double)oy + vy);
     p.s.own_x[e] = ox; p.s.own_y[e] = oy;
     p.s.own_h[e] = hd; p.s.own_s[e] = sp;
     p.s.own_vx[e] = vx; p.s.own_vy[e] = vy;
-    p.s.step_count[e] = ctr + 1u;
     /* dist(drone, goal): float32 - float64 -> float64 with the BLAS ddot FMA form */
     const double dx = (double)ox - gx, dy = (double)oy - gy;
     const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
@@ -612,16 +658,17 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
     sh->own_x = ox; sh->own_y = oy;
     sh->goal_hit = hit ? 1u : 0u;
     sh->rew_tail = hit ? (float)p.goal_rew : (p.sparse_reward ? (float)p.step_pen : (float)(-dg / p.dense_div));
-    sh->ctr = ctr;
     obs_tail(p, ox, oy, vx, vy, sp, hd, gx, gy, sh->tail);
 }
 
-/* ------------------------------------------------------------------ the fused step kernel */
-template <bool POS64, int RNG, bool RI>
-__global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams p)
+/* ------------------------------------------------------------------ the fused step kernel
+ * LDS: [E] EnvShare records, then (aligned obs only) E*D floats of obs staging. */
+template <bool POS64, int RNG, bool RI, bool SH>
+__global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
 {
     typedef typename PosT<POS64>::type P;
-    extern __shared__ EnvShare lds_env[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    EnvShare* lds_env = (EnvShare*)lds_raw;
     const int tid = threadIdx.x;
     const int L = p.L;
     const int g = tid >> p.lshift, gl = tid & (L - 1);
@@ -631,8 +678,8 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
     /* prefetch this lane's quad: independent of phase A, overlaps its latency */
-    Quad<POS64> q;
-    quad_load<POS64>(p, base, quad_ok, p.hold_sh, q);
+    Quad<POS64, SH> q;
+    quad_load<POS64, SH>(p, base, quad_ok, q);
 
     /* ---- phase A: ownship kinematics + env-level reward tail, one thread per env */
     if (tid < p.E) {
@@ -640,35 +687,46 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
         if (e < p.B) own_update<RNG>(p, e, &lds_env[tid]);
     }
     __syncthreads();
-    if (!env_ok) return;
+    if (UAM_ABLATE & 8) return;
 
-    const EnvShare& sh = lds_env[g];
+    /* a whole wave past the batch end has nothing to do (no barrier follows) */
+    const int wave_first_g = (tid & ~63) >> p.lshift;
+    const int env_first = blockIdx.x * p.E + wave_first_g;
+    if (env_first >= p.B) return;
+
+    const EnvShare& sh = lds_env[env_ok ? g : 0];
     const float ox = sh.own_x, oy = sh.own_y;
-    const uint32_t ctr = sh.ctr;
 
     /* ---- phase B: intruder sweep, _terminal_reward :146-168 (RandIntruder :181-204) */
     P nx[4], ny[4];
-    bool conf[4], nm[4], oob[4], valid[4];
+    uint32_t confm = 0, oobm = 0, validm = 0;
     uint32_t first_nmac = 0xFFFFu;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t idx = 4u * gl + j;
-        valid[j] = quad_ok && idx < (uint32_t)p.N;
+        const bool valid = quad_ok && idx < (uint32_t)p.N;
         const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
         float ax = q.vx[j], ay = q.vy[j];
         if (RI) { ax = ax + p.psig32; ay = ay + p.psig32; }     /* velocity + position_sigma, float32 */
+        bool oob;
         if (POS64 && prom) {
             nx[j] = (P)((double)q.x[j] + (double)ax);
             ny[j] = (P)((double)q.y[j] + (double)ay);
-            oob[j] = !((double)nx[j] >= 0.0 && (double)ny[j] >= 0.0 && (double)nx[j] <= (double)p.W32 &&
-                       (double)ny[j] <= (double)p.H32);
+            oob = !((double)nx[j] >= 0.0 && (double)ny[j] >= 0.0 && (double)nx[j] <= (double)p.W32 &&
+                    (double)ny[j] <= (double)p.H32);
         } else {
             const float fx = (float)q.x[j] + ax, fy = (float)q.y[j] + ay;
             nx[j] = (P)fx; ny[j] = (P)fy;
-            oob[j] = !(fx >= 0.f && fy >= 0.f && fx <= p.W32 && fy <= p.H32);   /* Box.contains, inclusive */
+            oob = !(fx >= 0.f && fy >= 0.f && fx <= p.W32 && fy <= p.H32);   /* Box.contains, inclusive */
         }
-        dist_flags<POS64>(ox, oy, nx[j], ny[j], prom, p, conf[j], nm[j]);
-        if (valid[j] && nm[j] && first_nmac == 0xFFFFu) first_nmac = idx;
+        bool conf, nm;
+        dist_flags<POS64>(ox, oy, nx[j], ny[j], prom, p, conf, nm);
+        if (valid) {
+            validm |= 1u << j;
+            if (conf) confm |= 1u << j;
+            if (oob) oobm |= 1u << j;
+            if (nm && first_nmac == 0xFFFFu) first_nmac = idx;
+        }
     }
     /* first NMAC index of the env: everything after it is untouched this step (:167-168) */
     const uint32_t kmin = grp_min(first_nmac, L);
@@ -676,44 +734,37 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t idx = 4u * gl + j;
-        const bool commit = valid[j] && idx <= kmin;
-        if (commit) {
-            const bool oldflag = (q.flags >> j) & 1u;
-            if (conf[j]) {
-                packed += 0x10000u + (oldflag ? 0u : 1u);     /* conflict=True; first-time flag -> no_conflict += 1 */
+        if (((validm >> j) & 1u) && idx <= kmin) {
+            if ((confm >> j) & 1u) {
+                packed += 0x10000u + (((q.flags >> j) & 1u) ? 0u : 1u);   /* first-time flag -> no_conflict += 1 */
                 q.flags |= 1u << j;
             }
             q.x[j] = nx[j]; q.y[j] = ny[j];
-            if (oob[j]) resp |= 1u << j;                       /* slot replaced by reset_intruder(), :151-152 */
+            if ((oobm >> j) & 1u) resp |= 1u << j;             /* slot replaced by reset_intruder(), :151-152 */
         }
     }
     packed = grp_add(packed, L);
+    if (UAM_ABLATE & 4) resp = 0;
     const bool nmac_any = kmin != 0xFFFFu;
     const bool conf_any = (packed >> 16) != 0;
     const uint32_t new_conf = packed & 0xFFFFu;
 
     Rng<RNG> rng;
-    rng.gid = p.gid0 + (uint32_t)env; rng.ctr = ctr; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+    rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
     bool vel_dirty = false;
     bool mt_used = false;
 
     /* ---- respawn */
-    if (RNG == UAM_RNG_PHILOX) {
+    if constexpr (RNG == UAM_RNG_PHILOX) {
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
             spawn_intruder<POS64, RNG>(p, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (k == j) {
-                    q.x[k] = X; q.y[k] = Y; q.vx[k] = vx; q.vy[k] = vy; q.sp[k] = sp; q.hd[k] = hd;
-                    q.flags &= ~((1u << k) | (1u << (4 + k)));
-                    q.flags |= (prom ? 1u : 0u) << (4 + k);
-                }
+            q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true;
         }
-    } else {
+    } else if (env_ok) {
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         for (;;) {
@@ -724,15 +775,8 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
             P X, Y; bool prom; float vx, vy; double sp, hd;
             spawn_intruder<POS64, RNG>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             if (mine == nxt) {
-                const int j = (int)(nxt & 3u);
-                resp &= ~(1u << j);
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (k == j) {
-                        q.x[k] = X; q.y[k] = Y; q.vx[k] = vx; q.vy[k] = vy; q.sp[k] = sp; q.hd[k] = hd;
-                        q.flags &= ~((1u << k) | (1u << (4 + k)));
-                        q.flags |= (prom ? 1u : 0u) << (4 + k);
-                    }
+                resp &= ~(1u << (nxt & 3u));
+                q.set((int)(nxt & 3u), X, Y, prom, vx, vy, sp, hd);
                 vel_dirty = true;
             }
         }
@@ -748,49 +792,55 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
     else { reward = sh.rew_tail; done = false; info = UAM_INFO_NONE; }
 
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
-    if (RI) {
-        if (RNG == UAM_RNG_PHILOX) {
+    if (RI && env_ok) {
+        if constexpr (RNG == UAM_RNG_PHILOX) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t idx = 4u * gl + j;
-                if (quad_ok && idx < (uint32_t)p.N) {
-                    bool take; double ud;
-                    rng.headchg(idx, p.hc_prob, take, ud);
-                    if (take) {
-                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
-                        q.hd[j] = q.hd[j] + deg * UAM_DEG2RAD;
-                        double sn, cs;
-                        uam_sincos(q.hd[j], &sn, &cs);
-                        q.vx[j] = (float)(q.sp[j] * cs);
-                        q.vy[j] = (float)(q.sp[j] * sn);
-                        vel_dirty = true;
+            for (int m = 0; m < 2; m++) {          /* one Philox block per intruder pair */
+                const uint32_t pair = 2u * gl + m;
+                if (quad_ok && 2u * pair < (uint32_t)p.N) {
+                    uint32_t w[4];
+                    rng.block(false, UAM_PH_HEADCHG, pair, 0, w);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int j = 2 * m + h;
+                        if (4u * gl + j < (uint32_t)p.N && uam_u32d(w[2 * h]) < p.hc_prob) {
+                            const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * uam_u32d(w[2 * h + 1]);
+                            q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
+                            double sn, cs;
+                            uam_sincos(q.hd[SH ? j : 0], &sn, &cs);
+                            q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
+                            q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
+                            vel_dirty = true;
+                        }
                     }
                 }
             }
         } else {
             if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             for (int i = 0; i < p.N; i++) {
-                bool take; double ud;
-                rng.headchg((uint32_t)i, p.hc_prob, take, ud);
-                if (take && (i >> 2) == gl) {
-                    const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                const double pr = 0.0 + 1.0 * mt_double(rng.m);
+                if (pr < p.hc_prob) {
+                    const double ud = mt_double(rng.m);
+                    if ((i >> 2) == gl) {
+                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if ((i & 3) == j) {
-                            q.hd[j] = q.hd[j] + deg * UAM_DEG2RAD;
-                            double sn, cs;
-                            uam_sincos(q.hd[j], &sn, &cs);
-                            q.vx[j] = (float)(q.sp[j] * cs);
-                            q.vy[j] = (float)(q.sp[j] * sn);
-                        }
-                    vel_dirty = true;
+                        for (int j = 0; j < 4; j++)
+                            if ((i & 3) == j) {
+                                q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
+                                double sn, cs;
+                                uam_sincos(q.hd[SH ? j : 0], &sn, &cs);
+                                q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
+                                q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
+                            }
+                        vel_dirty = true;
+                    }
                 }
             }
         }
     }
 
     /* ---- per-env outputs (one lane per env) */
-    if (gl == 0) {
+    if (env_ok && gl == 0) {
         p.reward[env] = reward;
         p.done[env] = done ? 1 : 0;
         if (p.info) p.info[env] = (uint8_t)info;
@@ -802,81 +852,100 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_step_kernel(const UamParams
     for (int k = 0; k < 8; k++) tail[k] = sh.tail[k];
 
     /* ---- VecEnv auto-reset: the obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
-    if (done && p.auto_reset) {
+    if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        reset_env<POS64, RNG>(p, env, gl, quad_ok, ctr + 1u, rng, q, tail);
+        reset_env<POS64, RNG, SH>(p, env, gl, quad_ok, rng, q, tail);
         vel_dirty = true;
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
 
     /* ---- commit state + obs pack */
     if (quad_ok) {
-        quad_store_pos<POS64>(p, base, q);
-        if (vel_dirty) quad_store_vel<POS64>(p, base, p.hold_sh, q);
+        if (!(UAM_ABLATE & 16)) quad_store_pos<POS64, SH>(p, base, q);
+        if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
-    if (p.obs) {
-        float* row = p.obs + (size_t)env * p.D;
-        if (quad_ok) {
-            const int nvalid = min(4, p.N - 4 * gl);
-            quad_obs<POS64>(p, row, 4 * gl, nvalid, q);
-        }
-        store_tail(p, row, gl, tail);
+    if (p.obs && !(UAM_ABLATE & 2)) {
+        float* stage = (float*)(lds_raw + (size_t)p.E * sizeof(EnvShare)) + (size_t)wave_first_g * p.D;
+        obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
     }
 }
 
-/* reset kernel: uam_reset (all envs or mask) */
-template <bool POS64, int RNG>
+/* reset kernel: uam_reset (all envs or mask).  LDS: E*D floats of obs staging (aligned obs only). */
+template <bool POS64, int RNG, bool SH>
 __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const int g = tid >> p.lshift, gl = tid & (p.L - 1);
     const int env = blockIdx.x * p.E + g;
-    if (env >= p.B) return;
-    if (p.mask && !p.mask[env]) return;
-    const bool quad_ok = gl < p.Q;
+    const int wave_first_g = (tid & ~63) >> p.lshift;
+    const int env_first = blockIdx.x * p.E + wave_first_g;
+    if (env_first >= p.B) return;
+    const bool env_ok = env < p.B;
+    const bool quad_ok = env_ok && gl < p.Q;
+    const bool sel = env_ok && !(p.mask && !p.mask[env]);
     const size_t base = (size_t)env * p.Np + 4u * gl;
-    Quad<POS64> q;
-    quad_load<POS64>(p, base, false, false, q);
-    Rng<RNG> rng;
-    rng.gid = p.gid0 + (uint32_t)env; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
-    const uint32_t ctr = p.s.step_count[env];
-    rng.load(p.s, env);
+    Quad<POS64, SH> q;
+    quad_load<POS64, SH>(p, base, quad_ok && !sel, q);   /* un-masked envs keep (and re-emit) their state */
     float tail[8];
-    /* every lane must have read step_count before lane 0 overwrites it */
-    __builtin_amdgcn_wave_barrier();
-    reset_env<POS64, RNG>(p, env, gl, quad_ok, ctr, rng, q, tail);
-    if (gl == 0) rng.store(p.s, env);
-    if (quad_ok) {
-        quad_store_pos<POS64>(p, base, q);
-        quad_store_vel<POS64>(p, base, p.hold_sh, q);
-        p.s.qf[base >> 2] = (uint8_t)q.flags;
+    if (sel) {
+        Rng<RNG> rng;
+        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+        rng.load(p.s, env);
+        reset_env<POS64, RNG, SH>(p, env, gl, quad_ok, rng, q, tail);
+        if (gl == 0) rng.store(p.s, env);
+        if (quad_ok) {
+            quad_store_pos<POS64, SH>(p, base, q);
+            quad_store_vel<POS64, SH>(p, base, q);
+            p.s.qf[base >> 2] = (uint8_t)q.flags;
+        }
+    } else if (env_ok) {
+        obs_tail(p, p.s.own_x[env], p.s.own_y[env], p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
+                 p.s.goal_x[env], p.s.goal_y[env], tail);
     }
     if (p.obs) {
-        float* row = p.obs + (size_t)env * p.D;
-        if (quad_ok) quad_obs<POS64>(p, row, 4 * gl, min(4, p.N - 4 * gl), q);
-        store_tail(p, row, gl, tail);
+        float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
+        obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
     }
 }
 
 /* observation of the current state, no stepping */
-template <bool POS64>
+template <bool POS64, bool SH>
 __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_observe_kernel(const UamParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const int g = tid >> p.lshift, gl = tid & (p.L - 1);
     const int env = blockIdx.x * p.E + g;
-    if (env >= p.B) return;
-    const bool quad_ok = gl < p.Q;
+    const int wave_first_g = (tid & ~63) >> p.lshift;
+    const int env_first = blockIdx.x * p.E + wave_first_g;
+    if (env_first >= p.B) return;
+    const bool env_ok = env < p.B;
+    const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
-    Quad<POS64> q;
-    quad_load<POS64>(p, base, quad_ok, p.hold_sh, q);
+    Quad<POS64, SH> q;
+    quad_load<POS64, SH>(p, base, quad_ok, q);
     float tail[8];
-    obs_tail(p, p.s.own_x[env], p.s.own_y[env], p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
-             p.s.goal_x[env], p.s.goal_y[env], tail);
-    float* row = p.obs + (size_t)env * p.D;
-    if (quad_ok) quad_obs<POS64>(p, row, 4 * gl, min(4, p.N - 4 * gl), q);
-    store_tail(p, row, gl, tail);
+    if (env_ok)
+        obs_tail(p, p.s.own_x[env], p.s.own_y[env], p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
+                 p.s.goal_x[env], p.s.goal_y[env], tail);
+    float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
+    obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+}
+
+/* ownship noise drawn ahead for K consecutive steps (Philox): out[k*B + e] = (zh, zs) of step base+k.
+ * Fully lane-parallel and off the step kernel's critical path; the values are exactly what the
+ * step would have drawn itself (counter-based RNG). */
+__global__ void __launch_bounds__(256) uam_noise_kernel(const UamParams p, double2* out, uint32_t base, int K)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)K * p.B) return;
+    const uint32_t k = (uint32_t)(t / (size_t)p.B);
+    const uint32_t e = (uint32_t)(t - (size_t)k * p.B);
+    double zh, zs;
+    uam_philox_normals(p.gid0 + e, base + k, p.seed_lo, p.seed_hi, zh, zs);
+    out[t] = make_double2(zh, zs);
 }
 
 /* built-in policies (bench / smoke utilities): thread per env */

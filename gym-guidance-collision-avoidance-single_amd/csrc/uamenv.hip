@@ -16,6 +16,7 @@
 #include "uam_device.h"
 
 static thread_local char g_err[512] = "";
+static const int NOISE_AHEAD = 16;   /* steps of ownship noise produced per uam_noise_kernel launch */
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -37,6 +38,10 @@ struct uam_env {
     uam_config cfg;
     int device;
     int Np, Q, L, lshift, T, E, D, hold_sh;
+    uint32_t step_index;        /* uam_step calls so far */
+    double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
+    uint32_t noise_base;        /* step index of noise row 0 */
+    bool noise_valid;
     UamDev s;
     std::vector<void*> allocs;
     hipEvent_t ev0, ev1;
@@ -142,10 +147,14 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->vmax32 = (float)c.max_speed; p->vden32 = (float)(c.max_speed * 2);
     p->psig32 = (float)c.position_sigma;
     p->min_sep32 = (float)c.minimum_separation; p->nmac32 = (float)c.nmac_dist; p->init_min32 = (float)c.initial_min_dist;
+    p->inv_2vmax = 1.0 / (c.max_speed * 2); p->inv_vrange = 1.0 / (c.max_speed - c.min_speed);
+    p->inv_W = 1.0 / c.window_width; p->inv_H = 1.0 / c.window_height;
+    p->step_index = e->step_index;
 }
 
 static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
-static inline size_t lds_of(const uam_env* e) { return (size_t)e->E * sizeof(EnvShare); }
+static inline size_t lds_stage(const uam_env* e, const UamParams& p) { return p.obs_vec ? (size_t)e->E * e->D * 4 : 0; }
+static inline size_t lds_step(const uam_env* e, const UamParams& p) { return (size_t)e->E * sizeof(EnvShare) + lds_stage(e, p); }
 
 extern "C" int uam_seed(uam_env* e, const uint64_t* seeds);
 
@@ -169,6 +178,10 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->timing = false;
     e->timed_launches = 0;
     e->policy_calls = 0;
+    e->step_index = 0;
+    e->noise = nullptr;
+    e->noise_base = 0;
+    e->noise_valid = false;
     e->ev0 = nullptr; e->ev1 = nullptr;
     const int B = cfg->num_envs, N = cfg->num_intruders;
     e->Np = (N + 3) & ~3;
@@ -178,6 +191,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->L = L; e->lshift = ls;
     /* block size: as large as 512 while the grid still has >= 1024 blocks (4 per CU), never below a wave */
     int T = UAM_MAX_BLOCK;
+    if (const char* tb = getenv("UAMENV_BLOCK")) T = atoi(tb);   /* development override */
+    if (T > UAM_MAX_BLOCK || T < 64 || (T & (T - 1))) T = UAM_MAX_BLOCK;
     while (T > 64 && T > L && ((int64_t)B * L + T - 1) / T < 1024) T >>= 1;
     if (T < L) T = L;
     if (T < 64) T = 64;
@@ -216,7 +231,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (!rc) rc = dev_alloc(e, &e->s.goal_x, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.goal_y, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
-    if (!rc) rc = dev_alloc(e, &e->s.step_count, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.reset_count, (size_t)B);
+    if (cfg->rng_mode == UAM_RNG_PHILOX && !rc) rc = dev_alloc(e, &e->noise, (size_t)B * NOISE_AHEAD);
     if (cfg->rng_mode == UAM_RNG_MT19937) {
         if (!rc) rc = dev_alloc(e, &e->s.mt_key, (size_t)B * UAM_MT_N);
         if (!rc) rc = dev_alloc(e, &e->s.mt_pos, (size_t)B);
@@ -281,38 +297,51 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
     } else if (seeds) {
         e->cfg.seed = seeds[0];
     }
-    HIP_TRY(hipMemset(e->s.step_count, 0, (size_t)B * 4));
+    HIP_TRY(hipMemset(e->s.reset_count, 0, (size_t)B * 4));
+    e->step_index = 0;
+    e->noise_valid = false;
     return UAM_OK;
 }
 
-/* ---- kernel dispatch over (precision, rng, dynamics) ---- */
+/* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held) ---- */
 template <bool POS64, int RNG>
-static void launch_step_ri(const uam_env* e, const UamParams& p, hipStream_t st)
+static void launch_step_t(const uam_env* e, const UamParams& p, hipStream_t st)
 {
     dim3 grid(grid_of(e)), block(e->T);
+    const size_t lds = lds_step(e, p);
     if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER)
-        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, true>), grid, block, lds_of(e), st, p);
+        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, true, true>), grid, block, lds, st, p);
+    else if (e->hold_sh)
+        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false, true>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false>), grid, block, lds_of(e), st, p);
+        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false, false>), grid, block, lds, st, p);
 }
 
 static void launch_step(const uam_env* e, const UamParams& p, hipStream_t st)
 {
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
-    if (x && mt) launch_step_ri<true, UAM_RNG_MT19937>(e, p, st);
-    else if (x) launch_step_ri<true, UAM_RNG_PHILOX>(e, p, st);
-    else if (mt) launch_step_ri<false, UAM_RNG_MT19937>(e, p, st);
-    else launch_step_ri<false, UAM_RNG_PHILOX>(e, p, st);
+    if (x && mt) launch_step_t<true, UAM_RNG_MT19937>(e, p, st);
+    else if (x) launch_step_t<true, UAM_RNG_PHILOX>(e, p, st);
+    else if (mt) launch_step_t<false, UAM_RNG_MT19937>(e, p, st);
+    else launch_step_t<false, UAM_RNG_PHILOX>(e, p, st);
+}
+
+template <bool POS64, int RNG>
+static void launch_reset_t(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    const size_t lds = lds_stage(e, p);
+    if (e->hold_sh) hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, false>), grid, block, lds, st, p);
 }
 
 static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
 {
-    dim3 grid(grid_of(e)), block(e->T);
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
-    if (x && mt) hipLaunchKernelGGL((uam_reset_kernel<true, UAM_RNG_MT19937>), grid, block, 0, st, p);
-    else if (x) hipLaunchKernelGGL((uam_reset_kernel<true, UAM_RNG_PHILOX>), grid, block, 0, st, p);
-    else if (mt) hipLaunchKernelGGL((uam_reset_kernel<false, UAM_RNG_MT19937>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((uam_reset_kernel<false, UAM_RNG_PHILOX>), grid, block, 0, st, p);
+    if (x && mt) launch_reset_t<true, UAM_RNG_MT19937>(e, p, st);
+    else if (x) launch_reset_t<true, UAM_RNG_PHILOX>(e, p, st);
+    else if (mt) launch_reset_t<false, UAM_RNG_MT19937>(e, p, st);
+    else launch_reset_t<false, UAM_RNG_PHILOX>(e, p, st);
 }
 
 static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)
@@ -345,8 +374,22 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
+    if (e->cfg.rng_mode == UAM_RNG_PHILOX) {
+        /* ownship noise of the next NOISE_AHEAD steps in one lane-parallel launch (counter-based: the same
+         * values the step would draw itself), off the step kernel's critical path */
+        if (!e->noise_valid || e->step_index < e->noise_base || e->step_index - e->noise_base >= (uint32_t)NOISE_AHEAD) {
+            const size_t total = (size_t)NOISE_AHEAD * e->cfg.num_envs;
+            hipLaunchKernelGGL(uam_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, e->noise,
+                               e->step_index, NOISE_AHEAD);
+            HIP_TRY(hipGetLastError());
+            e->noise_base = e->step_index;
+            e->noise_valid = true;
+        }
+        p.noise = e->noise + (size_t)(e->step_index - e->noise_base) * e->cfg.num_envs;
+    }
     launch_step(e, p, st);
     HIP_TRY(hipGetLastError());
+    e->step_index++;
     if (e->timing) e->timed_launches++;
     return UAM_OK;
 }
@@ -400,8 +443,12 @@ extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)
     if (rc) return rc;
     p.obs = obs_out;
     dim3 grid(grid_of(e)), block(e->T);
-    if (e->cfg.precision == UAM_POS_EXACT) hipLaunchKernelGGL((uam_observe_kernel<true>), grid, block, 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((uam_observe_kernel<false>), grid, block, 0, (hipStream_t)stream, p);
+    const size_t lds = lds_stage(e, p);
+    const bool x = e->cfg.precision == UAM_POS_EXACT;
+    if (x && e->hold_sh) hipLaunchKernelGGL((uam_observe_kernel<true, true>), grid, block, lds, (hipStream_t)stream, p);
+    else if (x) hipLaunchKernelGGL((uam_observe_kernel<true, false>), grid, block, lds, (hipStream_t)stream, p);
+    else if (e->hold_sh) hipLaunchKernelGGL((uam_observe_kernel<false, true>), grid, block, lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((uam_observe_kernel<false, false>), grid, block, lds, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
@@ -545,7 +592,8 @@ extern "C" int uam_get_state(uam_env* e, uam_state_view* v)
     if (v->field) HIP_TRY(hipMemcpy(v->field, e->s.src, (size_t)B * sizeof(*v->field), hipMemcpyDeviceToHost))
     GET_ENV(own_x, own_x); GET_ENV(own_y, own_y); GET_ENV(own_heading, own_h); GET_ENV(own_speed, own_s);
     GET_ENV(own_vx, own_vx); GET_ENV(own_vy, own_vy); GET_ENV(goal_x, goal_x); GET_ENV(goal_y, goal_y);
-    GET_ENV(no_conflict, no_conflict); GET_ENV(step_count, step_count);
+    GET_ENV(no_conflict, no_conflict); GET_ENV(reset_count, reset_count);
+    v->step_index = e->step_index;
 #undef GET_ENV
     if (e->cfg.rng_mode == UAM_RNG_MT19937) {
         if (v->mt_key || v->mt_pos) {
@@ -651,7 +699,8 @@ extern "C" int uam_set_state(uam_env* e, const uam_state_view* v)
     if (v->field) HIP_TRY(hipMemcpy(e->s.dst, v->field, (size_t)B * sizeof(*v->field), hipMemcpyHostToDevice))
     SET_ENV(own_x, own_x); SET_ENV(own_y, own_y); SET_ENV(own_heading, own_h); SET_ENV(own_speed, own_s);
     SET_ENV(own_vx, own_vx); SET_ENV(own_vy, own_vy); SET_ENV(goal_x, goal_x); SET_ENV(goal_y, goal_y);
-    SET_ENV(no_conflict, no_conflict); SET_ENV(step_count, step_count);
+    SET_ENV(no_conflict, no_conflict); SET_ENV(reset_count, reset_count);
+    if (v->step_index != UINT64_MAX) { e->step_index = (uint32_t)v->step_index; e->noise_valid = false; }
 #undef SET_ENV
     if (e->cfg.rng_mode == UAM_RNG_MT19937) {
         if (v->mt_key || v->mt_pos) {

@@ -282,12 +282,16 @@ class BatchedSingleAircraftEnv:
             st[n] = np.zeros({"B": (B,), "BN": (B, N), "B624": (B, 624)}[shape], dtype=dt)
         v = capi.make_view(st, B, N)
         capi.check(self._lib.uam_get_state(self._h, C.byref(v)))
+        st["step_index"] = np.uint64(v.step_index)
         return st
 
     def set_state(self, st):
         B, N = self.num_envs, self.intruder_size
         arrs = {}
         for n, a in st.items():
+            if n == "step_index":
+                arrs[n] = int(a)
+                continue
             dt, _ = capi.STATE_FIELDS[n]
             arrs[n] = np.ascontiguousarray(a, dtype=dt)
         v = capi.make_view(arrs, B, N)

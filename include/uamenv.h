@@ -73,8 +73,9 @@ enum {
 
 /* ---- random number source ---- */
 enum {
-    UAM_RNG_PHILOX  = 0, /* counter-based Philox4x32-10 keyed by (seed; env, step, purpose/idx, attempt):
-                            order-free, sharding-invariant; the throughput mode */
+    UAM_RNG_PHILOX  = 0, /* counter-based Philox4x32-10 keyed by (seed; global env id, step index | episode
+                            counter, purpose/intruder, attempt): order-free, sharding-invariant; the
+                            throughput mode (scheme in DESIGN.md) */
     UAM_RNG_MT19937 = 1  /* one NumPy-legacy MT19937 stream per env, consumed in the reference's draw order
                             (rk_double / polar rk_gauss with cache).  Env e seeded with s reproduces the
                             reference run in a process that called np.random.seed(s). */
@@ -135,11 +136,13 @@ typedef struct uam_state_view {
     double  *own_heading, *own_speed, *own_vx, *own_vy;
     double  *goal_x, *goal_y;
     int32_t *no_conflict;               /* SingleAircraftEnv.py:94,160 */
-    uint32_t *step_count;               /* per-env counter used in the Philox key */
+    uint32_t *reset_count;              /* per-env episode counter used in the Philox key of reset draws */
     uint32_t *mt_key;                   /* [B*624] MT19937 words, NumPy get_state() layout (UAM_RNG_MT19937) */
     int32_t  *mt_pos;                   /* [B] */
     int32_t  *mt_has_gauss;             /* [B] */
     double   *mt_gauss;                 /* [B] */
+    uint64_t step_index;                /* scalar: uam_step calls so far (Philox key of the step draws); filled by
+                                           uam_get_state, applied by uam_set_state unless UINT64_MAX (= keep) */
 } uam_state_view;
 
 typedef struct uam_env uam_env;
@@ -162,7 +165,7 @@ int uam_destroy(uam_env* env);
 int uam_seed(uam_env* env, const uint64_t* seeds_host);
 
 /* Start new episodes: all envs (mask_dev == NULL) or those with mask_dev[e] != 0.
- * obs_out: float32[B, D] device, rows of un-masked envs are left untouched; may be NULL. */
+ * obs_out: float32[B, D] device or NULL; rows of un-masked envs receive their current observation. */
 int uam_reset(uam_env* env, const uint8_t* mask_dev, float* obs_out, void* stream);
 
 /* One env.step() for every env of the batch, fused into one kernel launch.

@@ -52,8 +52,9 @@ class UamStateView(C.Structure):
         ("own_x", C.c_void_p), ("own_y", C.c_void_p),
         ("own_heading", C.c_void_p), ("own_speed", C.c_void_p), ("own_vx", C.c_void_p), ("own_vy", C.c_void_p),
         ("goal_x", C.c_void_p), ("goal_y", C.c_void_p),
-        ("no_conflict", C.c_void_p), ("step_count", C.c_void_p),
+        ("no_conflict", C.c_void_p), ("reset_count", C.c_void_p),
         ("mt_key", C.c_void_p), ("mt_pos", C.c_void_p), ("mt_has_gauss", C.c_void_p), ("mt_gauss", C.c_void_p),
+        ("step_index", C.c_uint64),
     ]
 
 
@@ -67,7 +68,7 @@ STATE_FIELDS = {
     "own_heading": (np.float64, False), "own_speed": (np.float64, False),
     "own_vx": (np.float64, False), "own_vy": (np.float64, False),
     "goal_x": (np.float64, False), "goal_y": (np.float64, False),
-    "no_conflict": (np.int32, False), "step_count": (np.uint32, False),
+    "no_conflict": (np.int32, False), "reset_count": (np.uint32, False),
 }
 MT_FIELDS = {"mt_key": (np.uint32, 624), "mt_pos": (np.int32, 1), "mt_has_gauss": (np.int32, 1),
              "mt_gauss": (np.float64, 1)}
@@ -88,7 +89,11 @@ def make_view(st, B, N):
     v = UamStateView()
     v.struct_size = C.sizeof(UamStateView)
     v.num_envs, v.num_intruders = B, N
+    v.step_index = 0xFFFFFFFFFFFFFFFF   # keep
     for name, arr in st.items():
+        if name == "step_index":
+            v.step_index = int(arr)
+            continue
         assert arr.flags["C_CONTIGUOUS"]
         setattr(v, name, arr.ctypes.data)
     return v
@@ -210,10 +215,11 @@ class OracleBatch:
         st = alloc_state(self.B, self.N, with_mt)
         v = make_view(st, self.B, self.N)
         lib().orc_get_state(self._h, C.byref(v))
+        st["step_index"] = np.uint64(v.step_index)
         return st
 
     def set_state(self, st):
-        st = {k: np.ascontiguousarray(a) for k, a in st.items()}
+        st = {k: (a if k == "step_index" else np.ascontiguousarray(a)) for k, a in st.items()}
         v = make_view(st, self.B, self.N)
         lib().orc_set_state(self._h, C.byref(v))
 

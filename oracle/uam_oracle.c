@@ -105,13 +105,14 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-enum { PH_OWN_NOISE = 0, PH_SPAWN_POS = 1, PH_SPAWN_SH = 2, PH_RESET_POS = 3, PH_RESET_SH = 4,
-       PH_RESET_GOAL = 5, PH_HEADCHG = 6, PH_RESET_OWN = 8 };
+/* counter = (global env id, step_index | reset_count, purpose<<16 | idx, attempt) */
+enum { PH_OWN_NOISE = 0, PH_SPAWN = 1, PH_RESET_SPAWN = 3, PH_RESET_GOAL = 5, PH_HEADCHG = 6, PH_RESET_OWN = 8 };
 
 static double u53(uint32_t a, uint32_t b)
 {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
+static double u32d(uint32_t a) { return (double)a * 0x1p-32; }   /* [0, 1) with 32 random bits */
 static double u53_open0(uint32_t a, uint32_t b) /* (0, 1] */
 {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6) + 1.0) / 9007199254740992.0;
@@ -134,7 +135,7 @@ typedef struct {
     int own_v_f32;                  /* velocity is still the float32 array of Aircraft.__init__ (:277) */
     double goal_x, goal_y;
     int32_t no_conflict;
-    uint32_t step_count;
+    uint32_t reset_count;           /* episodes started so far: Philox counter of the reset draws */
     mt_state* mt;                   /* own stream, or the shared one */
     int64_t spawns, redraws;
 } env_t;
@@ -144,6 +145,7 @@ struct orc_batch {
     int math_impl, shared;
     int B, N, D;
     int nthreads;
+    uint32_t step_index;            /* orc_step calls so far: Philox counter of the step draws */
     env_t* env;
     intruder_t* pool;
     mt_state* mts;
@@ -184,7 +186,8 @@ static double mt_gauss(const orc_batch* b, mt_state* s)
 
 static void philox(const ctx_t* c, uint32_t purpose, uint32_t idx, uint32_t attempt, uint32_t out[4])
 {
-    uint32_t ctr[4] = { c->gid, c->e->step_count, (purpose << 16) | idx, attempt };
+    const int reset_phase = purpose == PH_RESET_SPAWN || purpose == PH_RESET_GOAL || purpose == PH_RESET_OWN;
+    uint32_t ctr[4] = { c->gid, reset_phase ? c->e->reset_count : c->b->step_index, (purpose << 16) | idx, attempt };
     uint32_t key[2] = { (uint32_t)c->b->cfg.seed, (uint32_t)(c->b->cfg.seed >> 32) };
     orc_philox4x32_10(ctr, key, out);
 }
@@ -230,12 +233,12 @@ static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t*
         speed = g->min_speed + (g->max_speed - g->min_speed) * mt_double(e->mt);
         heading = 0.0 + (2.0 * M_PI - 0.0) * mt_double(e->mt);
     } else {
-        philox(c, reset_phase ? PH_RESET_POS : PH_SPAWN_POS, (uint32_t)idx, 0, w);
-        px = 0.0 + g->window_width * u53(w[0], w[1]);
-        py = 0.0 + g->window_height * u53(w[2], w[3]);
-        philox(c, reset_phase ? PH_RESET_SH : PH_SPAWN_SH, (uint32_t)idx, 0, w);
-        speed = g->min_speed + (g->max_speed - g->min_speed) * u53(w[0], w[1]);
-        heading = 0.0 + (2.0 * M_PI - 0.0) * u53(w[2], w[3]);
+        /* one Philox call per spawn: 32 random bits per quantity */
+        philox(c, reset_phase ? PH_RESET_SPAWN : PH_SPAWN, (uint32_t)idx, 0, w);
+        px = 0.0 + g->window_width * u32d(w[0]);
+        py = 0.0 + g->window_height * u32d(w[1]);
+        speed = g->min_speed + (g->max_speed - g->min_speed) * u32d(w[2]);
+        heading = 0.0 + (2.0 * M_PI - 0.0) * u32d(w[3]);
     }
     double sn, cs;
     m_sincos(b, heading, &sn, &cs);
@@ -255,9 +258,9 @@ static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t*
             px = 0.0 + g->window_width * mt_double(e->mt);
             py = 0.0 + g->window_height * mt_double(e->mt);
         } else {
-            philox(c, reset_phase ? PH_RESET_POS : PH_SPAWN_POS, (uint32_t)idx, attempt, w);
-            px = 0.0 + g->window_width * u53(w[0], w[1]);
-            py = 0.0 + g->window_height * u53(w[2], w[3]);
+            philox(c, reset_phase ? PH_RESET_SPAWN : PH_SPAWN, (uint32_t)idx, attempt, w);
+            px = 0.0 + g->window_width * u32d(w[0]);
+            py = 0.0 + g->window_height * u32d(w[1]);
         }
         if (g->precision == UAM_POS_EXACT) { out->x = px; out->y = py; out->promoted = 1; }
         else { out->x = (double)(float)px; out->y = (double)(float)py; }
@@ -281,11 +284,10 @@ static void env_reset(const ctx_t* c)
         } else {
             uint32_t w[4];
             philox(c, PH_RESET_OWN, 0, 0, w);
-            ox = 0.0 + g->window_width * u53(w[0], w[1]);
-            oy = 0.0 + g->window_height * u53(w[2], w[3]);
-            philox(c, PH_RESET_OWN, 1, 0, w);
-            osp = g->min_speed + (g->max_speed - g->min_speed) * u53(w[0], w[1]);
-            ohd = 0.0 + (2.0 * M_PI - 0.0) * u53(w[2], w[3]);
+            ox = 0.0 + g->window_width * u32d(w[0]);
+            oy = 0.0 + g->window_height * u32d(w[1]);
+            osp = g->min_speed + (g->max_speed - g->min_speed) * u32d(w[2]);
+            ohd = 0.0 + (2.0 * M_PI - 0.0) * u32d(w[3]);
         }
     }
     e->own_x = (float)ox;
@@ -303,11 +305,11 @@ static void env_reset(const ctx_t* c)
     } else {
         uint32_t w[4];
         philox(c, PH_RESET_GOAL, 0, 0, w);
-        e->goal_x = 0.0 + g->window_width * u53(w[0], w[1]);
-        e->goal_y = 0.0 + g->window_height * u53(w[2], w[3]);
+        e->goal_x = 0.0 + g->window_width * u32d(w[0]);
+        e->goal_y = 0.0 + g->window_height * u32d(w[1]);
     }
     e->no_conflict = 0;
-    e->step_count++;
+    e->reset_count++;
 }
 
 /* _get_ob, :98-124 (NORM4); SingleAircraftMCTSEnv.py:98-124 (RAW4);
@@ -447,11 +449,11 @@ static void update_headings(const ctx_t* c)
             take = p < g->heading_change_prob;
             ud = take ? mt_double(e->mt) : 0.0;
         } else {
-            uint32_t w[4];
-            philox(c, PH_HEADCHG, (uint32_t)i, 0, w);
-            p = u53(w[0], w[1]);
+            uint32_t w[4];   /* one call serves the intruder pair (2m, 2m+1) */
+            philox(c, PH_HEADCHG, (uint32_t)(i >> 1), 0, w);
+            p = u32d(w[2 * (i & 1)]);
             take = p < g->heading_change_prob;
-            ud = u53(w[2], w[3]);
+            ud = u32d(w[2 * (i & 1) + 1]);
         }
         if (take) {
             double deg = -g->heading_change_max_deg + (g->heading_change_max_deg - (-g->heading_change_max_deg)) * ud;
@@ -488,7 +490,6 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
     double r; int d, inf;
     terminal_reward(c, &r, &d, &inf);
     if (g->dynamics == UAM_DYN_RANDINTRUDER) update_headings(c);
-    c->e->step_count++;
     if (d && g->auto_reset) env_reset(c);
     if (obs) env_obs(b, c->e, obs);
     reward[eidx] = r;
@@ -537,7 +538,8 @@ int orc_seed(orc_batch* b, const uint64_t* seeds)
     } else if (seeds) {
         b->cfg.seed = seeds[0];
     }
-    for (int e = 0; e < b->B; e++) b->env[e].step_count = 0;
+    for (int e = 0; e < b->B; e++) b->env[e].reset_count = 0;
+    b->step_index = 0;
     return 0;
 }
 
@@ -566,6 +568,7 @@ void orc_step(orc_batch* b, const void* actions, double* obs_out, double* reward
         ctx_t c = { b, &b->env[e], (uint32_t)((uint64_t)b->cfg.env_id_offset + (uint64_t)e) };
         env_step(&c, e, actions, obs_out ? obs_out + (size_t)e * b->D : NULL, reward_out, done_out, info_out);
     }
+    b->step_index++;
 }
 
 void orc_observe(orc_batch* b, double* obs_out)
@@ -588,6 +591,7 @@ int64_t orc_redraw_count(const orc_batch* b)
 
 void orc_get_state(orc_batch* b, uam_state_view* v)
 {
+    v->step_index = b->step_index;
     for (int e = 0; e < b->B; e++) {
         const env_t* en = &b->env[e];
         for (int i = 0; i < b->N; i++) {
@@ -611,7 +615,7 @@ void orc_get_state(orc_batch* b, uam_state_view* v)
         if (v->goal_x) v->goal_x[e] = en->goal_x;
         if (v->goal_y) v->goal_y[e] = en->goal_y;
         if (v->no_conflict) v->no_conflict[e] = en->no_conflict;
-        if (v->step_count) v->step_count[e] = en->step_count;
+        if (v->reset_count) v->reset_count[e] = en->reset_count;
         if (b->mts && !b->shared) {
             const mt_state* m = en->mt;
             if (v->mt_key) memcpy(v->mt_key + (size_t)e * MT_N, m->key, sizeof(m->key));
@@ -624,6 +628,7 @@ void orc_get_state(orc_batch* b, uam_state_view* v)
 
 void orc_set_state(orc_batch* b, const uam_state_view* v)
 {
+    if (v->step_index != UINT64_MAX) b->step_index = (uint32_t)v->step_index;   /* UINT64_MAX = keep */
     for (int e = 0; e < b->B; e++) {
         env_t* en = &b->env[e];
         for (int i = 0; i < b->N; i++) {
@@ -647,7 +652,7 @@ void orc_set_state(orc_batch* b, const uam_state_view* v)
         if (v->goal_x) en->goal_x = v->goal_x[e];
         if (v->goal_y) en->goal_y = v->goal_y[e];
         if (v->no_conflict) en->no_conflict = v->no_conflict[e];
-        if (v->step_count) en->step_count = v->step_count[e];
+        if (v->reset_count) en->reset_count = v->reset_count[e];
         if (b->mts && !b->shared) {
             mt_state* m = en->mt;
             if (v->mt_key) memcpy(m->key, v->mt_key + (size_t)e * MT_N, sizeof(m->key));

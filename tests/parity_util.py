@@ -3,7 +3,7 @@ CPU oracle with identical configs, seeds and actions, and compare them step by s
 import numpy as np
 
 STATE_EXACT = ["int_x", "int_y", "int_vx", "int_vy", "int_conflict", "int_promoted", "own_x", "own_y",
-               "own_heading", "own_speed", "own_vx", "own_vy", "goal_x", "goal_y", "no_conflict", "step_count"]
+               "own_heading", "own_speed", "own_vx", "own_vy", "goal_x", "goal_y", "no_conflict", "reset_count", "step_index"]
 
 
 def oracle_cfg_from(oracle, cfg):
@@ -42,7 +42,7 @@ def compare_states(gs, os_, where, fields=None, hold_sh=False):
     for k in fields:
         if k not in gs or k not in os_:
             continue
-        a, b = gs[k], os_[k].astype(gs[k].dtype)
+        a, b = np.atleast_1d(gs[k]), np.atleast_1d(os_[k]).astype(np.asarray(gs[k]).dtype)
         if not np.array_equal(a, b):
             bad = np.argwhere(a != b)
             i = tuple(bad[0])
