@@ -5,20 +5,19 @@
  * observe / policy kernels and the two RNGs (Philox4x32-10, NumPy-legacy
  * MT19937 with lazy per-word twist).
  *
- * Execution shape (CDNA4, wave64):
- *   - one env is owned by a sub-wave group of L = next_pow2(ceil(N/4)) lanes;
- *     a lane owns a "quad" of 4 consecutive intruders, so every intruder field
- *     is moved with 16-byte (float32) / 2x16-byte (float64) accesses and a
- *     wave touches 1 KiB of contiguous SoA per instruction;
- *   - per-env fp64 work (ownship kinematics, noise, goal distance, obs tail) is
- *     done ONCE per env by the first E threads of the block (lane-per-env,
- *     coalesced over envs) and handed to the groups through LDS — doing it
- *     redundantly in every lane of a group would multiply the fp64 issue cost
- *     by 64/L;
- *   - the sequential semantics of the reference's intruder loop (NMAC early
- *     exit, flags, respawn order) are recovered with two in-group shuffle
- *     reductions (min index of the first NMAC, packed sum of new conflicts) and
- *     a predicated commit.
+ * Execution shape (CDNA4, wave64) — one env.step() is two dependent launches:
+ *   uam_own_kernel   one THREAD per env: the fp64 ownship kinematics, goal distance, env-level reward
+ *                    tail and the ownship/goal part of the observation (coalesced over envs); result
+ *                    handed over as a 48-byte record per env.  fp64 trig needs ~96 VGPRs; keeping it
+ *                    out of the sweep lets that kernel run at 8 waves/SIMD.
+ *   uam_sweep_kernel one env is owned by a sub-wave group of L = next_pow2(ceil(N/4)) lanes; a lane
+ *                    owns a "quad" of 4 consecutive intruders, so every intruder field moves with
+ *                    16-byte accesses and a wave touches 1 KiB of contiguous SoA per instruction.
+ *                    The sequential semantics of the reference's intruder loop (NMAC early exit,
+ *                    flags, respawn order) are recovered with two in-group shuffle reductions (min
+ *                    index of the first NMAC, packed sum of new conflicts) and a predicated commit.
+ *                    Observations are staged in LDS per wave and streamed out 1 KiB per instruction.
+ *   The ownship noise of the float32/Philox mode is drawn ahead for 16 steps by uam_noise_kernel.
  * Everything is compiled with -ffp-contract=off: the float32 sweep must not be
  * FMA-contracted and every fused operation is an explicit fma().
  *
@@ -64,6 +63,7 @@ struct UamDev {
     double*  goal_y;
     int32_t* no_conflict;
     uint32_t* reset_count; /* [B] episodes started so far: Philox counter of the reset draws */
+    float4*  share;     /* [B*3] OwnShare records handed from uam_own_kernel to uam_sweep_kernel */
     uint32_t* mt_key;   /* [B*624] */
     int32_t* mt_pos;    /* [B] next word to consume (624 = wrap first) */
     int32_t* mt_gen;    /* [B] words [0,gen) of the current round are already twisted */
@@ -71,17 +71,29 @@ struct UamDev {
     double*  mt_gauss;
 };
 
-struct UamParams {
-    UamDev s;
-    int B, N, Np, Q, L, lshift, E, D;
-    int obs_mode, action_mode, auto_reset, sparse_reward, random_own_start, obs_w, obs_vec, hold_sh;
-    uint32_t seed_lo, seed_hi, gid0;
+/* cold configuration (doubles; read by the ownship kernel and the rare spawn/reset paths) lives in a
+ * small device buffer so that the sweep kernel's hot path does not pin ~60 SGPRs of kernarg */
+struct UamCold {
     double W, H, min_sep, nmac, init_min, goal_r, min_speed, max_speed, d_speed, speed_sigma, d_heading,
         heading_sigma, nmac_pen, conf_pen, step_pen, goal_rew, dense_div, own_x0, own_y0, own_speed0,
         own_heading0, hc_prob, hc_max_deg;
-    float W32, H32, vmax32, vden32, psig32, min_sep32, nmac32, init_min32;
     double inv_2vmax, inv_vrange, inv_W, inv_H;   /* reciprocals for the float32 obs tail (tolerance, not parity) */
+    double own_vx0, own_vy0;      /* float32(own_speed0 * cos/sin(own_heading0)), SingleAircraftEnv.py:275-277 */
+    double sep2, nmac2, init2;    /* float64 squared-distance thresholds: min{v : sqrt(v) >= thr} */
+};
+
+struct UamParams {
+    UamDev s;
+    const UamCold* c;
+    int B, N, Np, Q, L, lshift, E, D;
+    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec;
+    uint32_t seed_lo, seed_hi, gid0;
     uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
+    float W32, H32, vmax32, psig32;
+    float sep2_32, nmac2_32, init2_32;   /* float32 squared-distance thresholds: min{v : sqrtf(v) >= thr} */
+    float inv_W32, inv_H32, inv_vden32;  /* reciprocals for the normalised float32 obs */
+    float nmac_pen32, conf_pen32;
+    float spawn_sx, spawn_sy, min_speed32, vrange32;   /* float32 spawn (lean Philox mode) */
     const double2* noise;         /* [B] (zh, zs) of this step, produced ahead by uam_noise_kernel (Philox) */
     /* per-call I/O (device pointers owned by the caller) */
     const void* actions;
@@ -95,12 +107,11 @@ struct UamParams {
     void* actions_out;
 };
 
-/* what phase A hands to the env's lane group through LDS (64 B per env) */
-struct EnvShare {
+/* what uam_own_kernel hands to the env's lane group (48 B per env, three float4) */
+struct OwnShare {
     float own_x, own_y;
     float rew_tail;      /* reward if neither NMAC nor conflict: goal reward or dense/sparse step reward */
     uint32_t goal_hit;
-    uint32_t pad[4];
     float tail[8];       /* ownship(6) + goal(2) part of the observation */
 };
 
@@ -290,7 +301,9 @@ __device__ __forceinline__ uint32_t grp_add(uint32_t v, int L)
 }
 
 /* np.linalg.norm(own - intruder) < thr, SingleAircraftEnv.py:312-313 + NEP-50 compare.
- * float32 pair: sqrtf(rn(dx*dx) + rn(dy*dy)) (no FMA); promoted: sqrt(fma(dy,dy,rn(dx*dx))). */
+ * float32 pair: sqrtf(rn(dx*dx) + rn(dy*dy)) (no FMA); promoted: sqrt(fma(dy,dy,rn(dx*dx))).
+ * sqrt is monotonic and correctly rounded on both sides, so `sqrt(d2) < thr` is decided exactly by
+ * `d2 < T2` with T2 = min{v : sqrt(v) >= thr} precomputed on the host: no sqrt in the sweep. */
 template <bool POS64>
 __device__ __forceinline__ void dist_flags(float ox, float oy, typename PosT<POS64>::type x,
                                            typename PosT<POS64>::type y, bool prom, const UamParams& p,
@@ -298,14 +311,14 @@ __device__ __forceinline__ void dist_flags(float ox, float oy, typename PosT<POS
 {
     if (POS64 && prom) {
         double dx = (double)ox - (double)x, dy = (double)oy - (double)y;
-        double d = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
-        conf = d < p.min_sep;
-        nmac = d < p.nmac;
+        double d2 = uam_fma(dy, dy, dx * dx);
+        conf = d2 < p.c->sep2;
+        nmac = d2 < p.c->nmac2;
     } else {
         float dx = ox - (float)x, dy = oy - (float)y;
-        float d = __builtin_sqrtf(dx * dx + dy * dy);
-        conf = d < p.min_sep32;
-        nmac = d < p.nmac32;
+        float d2 = dx * dx + dy * dy;
+        conf = d2 < p.sep2_32;
+        nmac = d2 < p.nmac2_32;
     }
 }
 
@@ -315,41 +328,66 @@ __device__ __forceinline__ bool too_close(float ox, float oy, typename PosT<POS6
 {
     if (POS64 && prom) {
         double dx = (double)ox - (double)x, dy = (double)oy - (double)y;
-        return __builtin_sqrt(uam_fma(dy, dy, dx * dx)) < p.init_min;
+        return uam_fma(dy, dy, dx * dx) < p.c->init2;
     }
     float dx = ox - (float)x, dy = oy - (float)y;
-    return __builtin_sqrtf(dx * dx + dy * dy) < p.init_min32;
+    return dx * dx + dy * dy < p.init2_32;
 }
 
-/* reset_intruder / spawn loop of reset(): SingleAircraftEnv.py:79-86, 230-251, 270-279 */
-template <bool POS64, int RNG>
+/* reset_intruder / spawn loop of reset(): SingleAircraftEnv.py:79-86, 230-251, 270-279.
+ * LEAN (float32 positions, Philox, speed/heading not held): the whole spawn is float32 arithmetic
+ * on the Philox words — x, y, speed with 24 random bits, heading with 26 via the quadrant sincos —
+ * so the sweep kernel carries no fp64 trig.  Otherwise the reference's float64 construction. */
+template <bool POS64, int RNG, bool LEAN>
 __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_t idx, bool reset_phase, float ox,
                                       float oy, typename PosT<POS64>::type& X, typename PosT<POS64>::type& Y,
                                       bool& prom, float& vx, float& vy, double& sp, double& hd)
 {
     typedef typename PosT<POS64>::type P;
     const uint32_t purpose = reset_phase ? UAM_PH_RESET_SPAWN : UAM_PH_SPAWN;
-    double u[4];
-    rng.quad(reset_phase, purpose, idx, u);
-    double fx = 0.0 + p.W * u[0], fy = 0.0 + p.H * u[1];
-    sp = p.min_speed + (p.max_speed - p.min_speed) * u[2];
-    hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
-    double sn, cs;
-    uam_sincos(hd, &sn, &cs);
-    vx = (float)(sp * cs);
-    vy = (float)(sp * sn);
-    X = (P)(float)fx;
-    Y = (P)(float)fy;
-    prom = false;
-    uint32_t attempt = 0;
-    while (too_close<POS64>(ox, oy, X, Y, prom, p)) {
-        attempt++;
-        double u1, u2;
-        rng.two(reset_phase, purpose, idx, attempt, u1, u2);
-        fx = 0.0 + p.W * u1;
-        fy = 0.0 + p.H * u2;
-        if (POS64) { X = (P)fx; Y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
-        else { X = (P)(float)fx; Y = (P)(float)fy; }
+    if constexpr (LEAN) {
+        uint32_t w[4];
+        rng.block(reset_phase, purpose, idx, 0, w);
+        float fx = (float)(w[0] >> 8) * p.spawn_sx, fy = (float)(w[1] >> 8) * p.spawn_sy;
+        const float u = (float)(w[2] >> 8) * 0x1p-24f;
+        const float spf = p.min_speed32 + p.vrange32 * u;
+        float sn, cs;
+        uam_sincos_turn_f32(w[3], &sn, &cs);
+        vx = spf * cs;
+        vy = spf * sn;
+        sp = 0.0; hd = 0.0;
+        prom = false;
+        uint32_t attempt = 0;
+        while (too_close<POS64>(ox, oy, (P)fx, (P)fy, false, p)) {
+            attempt++;
+            rng.block(reset_phase, purpose, idx, attempt, w);
+            fx = (float)(w[0] >> 8) * p.spawn_sx;
+            fy = (float)(w[1] >> 8) * p.spawn_sy;
+        }
+        X = (P)fx; Y = (P)fy;
+    } else {
+        double u[4];
+        rng.quad(reset_phase, purpose, idx, u);
+        double fx = 0.0 + p.c->W * u[0], fy = 0.0 + p.c->H * u[1];
+        sp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
+        hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
+        double sn, cs;
+        uam_sincos(hd, &sn, &cs);
+        vx = (float)(sp * cs);
+        vy = (float)(sp * sn);
+        X = (P)(float)fx;
+        Y = (P)(float)fy;
+        prom = false;
+        uint32_t attempt = 0;
+        while (too_close<POS64>(ox, oy, X, Y, prom, p)) {
+            attempt++;
+            double u1, u2;
+            rng.two(reset_phase, purpose, idx, attempt, u1, u2);
+            fx = 0.0 + p.c->W * u1;
+            fy = 0.0 + p.c->H * u2;
+            if (POS64) { X = (P)fx; Y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
+            else { X = (P)(float)fx; Y = (P)(float)fy; }
+        }
     }
 }
 
@@ -449,15 +487,16 @@ __device__ __forceinline__ void quad_obs(const UamParams& p, float* dst, bool ve
     for (int j = 0; j < 4; j++) {
         const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
         if (p.obs_mode == UAM_OBS_NORM4) {
+            /* float32 output within 1 ulp of the reference's quotient (reciprocal multiply) */
             if (prom) {
-                v[j][0] = (float)((double)q.x[j] / p.W);
-                v[j][1] = (float)((double)q.y[j] / p.H);
+                v[j][0] = (float)((double)q.x[j] * p.c->inv_W);
+                v[j][1] = (float)((double)q.y[j] * p.c->inv_H);
             } else {
-                v[j][0] = (float)q.x[j] / p.W32;
-                v[j][1] = (float)q.y[j] / p.H32;
+                v[j][0] = (float)q.x[j] * p.inv_W32;
+                v[j][1] = (float)q.y[j] * p.inv_H32;
             }
-            v[j][2] = (q.vx[j] + p.vmax32) / p.vden32;
-            v[j][3] = (q.vy[j] + p.vmax32) / p.vden32;
+            v[j][2] = (q.vx[j] + p.vmax32) * p.inv_vden32;
+            v[j][3] = (q.vy[j] + p.vmax32) * p.inv_vden32;
         } else {
             v[j][0] = (float)q.x[j]; v[j][1] = (float)q.y[j];
             v[j][2] = q.vx[j];       v[j][3] = q.vy[j];
@@ -495,14 +534,14 @@ __device__ __forceinline__ void obs_tail(const UamParams& p, float ox, float oy,
                                          double hd, double gx, double gy, float* t)
 {
     if (p.obs_mode == UAM_OBS_NORM4) {
-        t[0] = ox / p.W32;
-        t[1] = oy / p.H32;
-        t[2] = (float)((vx + p.max_speed) * p.inv_2vmax);
-        t[3] = (float)((vy + p.max_speed) * p.inv_2vmax);
-        t[4] = (float)((sp - p.min_speed) * p.inv_vrange);
+        t[0] = ox * p.inv_W32;
+        t[1] = oy * p.inv_H32;
+        t[2] = (float)((vx + p.c->max_speed) * p.c->inv_2vmax);
+        t[3] = (float)((vy + p.c->max_speed) * p.c->inv_2vmax);
+        t[4] = (float)((sp - p.c->min_speed) * p.c->inv_vrange);
         t[5] = (float)(hd * (1.0 / UAM_TWO_PI));
-        t[6] = (float)(gx * p.inv_W);
-        t[7] = (float)(gy * p.inv_H);
+        t[6] = (float)(gx * p.c->inv_W);
+        t[7] = (float)(gy * p.c->inv_H);
     } else {
         t[0] = ox; t[1] = oy; t[2] = (float)vx; t[3] = (float)vy;
         t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
@@ -550,28 +589,34 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, 
     }
 }
 
+/* which spawn arithmetic a kernel instance uses (see spawn_intruder) */
+#define UAM_LEAN(POS64, RNG, SH) (!(POS64) && (RNG) == UAM_RNG_PHILOX && !(SH))
+
 /* SingleAircraftEnv.reset (:64-96) for one env, executed by its lane group.
  * Philox: lane-parallel (every lane spawns its own quad); MT19937: the draws are
  * sequential, so the group walks i = 0..N-1 uniformly and the owner lane keeps
- * the result.  Stores the per-env fields (lane 0) and returns the obs tail. */
-template <bool POS64, int RNG, bool SH>
+ * the result.  Stores the per-env fields (lane 0) and returns the obs tail.
+ * ROS = SingleAircraftRandomEnv's random ownship start (needs fp64 trig here). */
+template <bool POS64, int RNG, bool SH, bool ROS>
 __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, Rng<RNG>& rng,
                                  Quad<POS64, SH>& q, float* tail)
 {
+    constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
     const uint32_t rc = p.s.reset_count[env];
     rng.c_reset = rc;
-    double ox = p.own_x0, oy = p.own_y0, osp = p.own_speed0, ohd = p.own_heading0;
-    if (p.random_own_start) {   /* SingleAircraftRandomEnv.py:70-74 */
+    double ox = p.c->own_x0, oy = p.c->own_y0, osp = p.c->own_speed0, ohd = p.c->own_heading0;
+    double ovx = p.c->own_vx0, ovy = p.c->own_vy0;
+    if constexpr (ROS) {   /* SingleAircraftRandomEnv.py:70-74 */
         double u[4];
         rng.quad(true, UAM_PH_RESET_OWN, 0, u);
-        ox = 0.0 + p.W * u[0]; oy = 0.0 + p.H * u[1];
-        osp = p.min_speed + (p.max_speed - p.min_speed) * u[2];
+        ox = 0.0 + p.c->W * u[0]; oy = 0.0 + p.c->H * u[1];
+        osp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
         ohd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
+        double sn, cs;
+        uam_sincos(ohd, &sn, &cs);
+        ovx = (double)(float)(osp * cs); ovy = (double)(float)(osp * sn);
     }
     const float oxf = (float)ox, oyf = (float)oy;
-    double sn, cs;
-    uam_sincos(ohd, &sn, &cs);
-    const double ovx = (double)(float)(osp * cs), ovy = (double)(float)(osp * sn);
     q.flags = 0;
     if constexpr (RNG == UAM_RNG_PHILOX) {
 #pragma unroll
@@ -579,20 +624,20 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
             const uint32_t idx = 4u * gl + j;
             if (quad_ok && idx < (uint32_t)p.N) {
                 typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
-                spawn_intruder<POS64, RNG>(p, rng, idx, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
+                spawn_intruder<POS64, RNG, LEAN>(p, rng, idx, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
                 q.set(j, X, Y, prom, vx, vy, sp, hd);
             }
         }
     } else {
         for (int i = 0; i < p.N; i++) {
             typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
             if ((i >> 2) == gl) q.set(i & 3, X, Y, prom, vx, vy, sp, hd);
         }
     }
     double g1, g2;
     rng.two(true, UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
-    const double gx = 0.0 + p.W * g1, gy = 0.0 + p.H * g2;
+    const double gx = 0.0 + p.c->W * g1, gy = 0.0 + p.c->H * g2;
     /* every lane of the group has read reset_count above; the group is one wave-resident unit */
     __builtin_amdgcn_wave_barrier();
     if (gl == 0) {
@@ -606,11 +651,14 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     obs_tail(p, oxf, oyf, ovx, ovy, osp, ohd, gx, gy, tail);
 }
 
-/* Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
- * one thread per env (phase A). */
+/* ------------------------------------------------------------------ launch 1: ownship kernel
+ * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
+ * one thread per env. */
 template <int RNG>
-__device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
+__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p)
 {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B) return;
     float ox = p.s.own_x[e], oy = p.s.own_y[e];
     double hd = p.s.own_h[e], sp = p.s.own_s[e];
     const double gx = p.s.goal_x[e], gy = p.s.goal_y[e];
@@ -628,8 +676,8 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
     }
     double zh, zs;
     if constexpr (RNG == UAM_RNG_PHILOX) {
-        if (UAM_ABLATE & 1) { zh = 0.25; zs = -0.125; }
-        else { const double2 z = p.noise[e]; zh = z.x; zs = z.y; }   /* drawn ahead by uam_noise_kernel */
+        const double2 z = p.noise[e];   /* drawn ahead by uam_noise_kernel */
+        zh = z.x; zs = z.y;
     } else {
         Rng<UAM_RNG_MT19937> rng;
         rng.load(p.s, e);
@@ -637,14 +685,13 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
         zs = mt_gauss(rng.m);
         rng.store(p.s, e);
     }
-    hd += p.d_heading * (a0 - 1.0);
-    hd += 0.0 + p.heading_sigma * zh;
-    if (has_speed) sp += p.d_speed * (a1 - 1.0);
-    sp = fmax(p.min_speed, fmin(sp, p.max_speed));
-    sp += 0.0 + p.speed_sigma * zs;
+    hd += p.c->d_heading * (a0 - 1.0);
+    hd += 0.0 + p.c->heading_sigma * zh;
+    if (has_speed) sp += p.c->d_speed * (a1 - 1.0);
+    sp = fmax(p.c->min_speed, fmin(sp, p.c->max_speed));
+    sp += 0.0 + p.c->speed_sigma * zs;
     double sn, cs;
-    if (UAM_ABLATE & 1) { sn = 0.6; cs = 0.8; }
-    else uam_sincos(hd, &sn, &cs);
+    uam_sincos(hd, &sn, &cs);
     const double vx = sp * cs, vy = sp * sn;
     ox = (float)((double)ox + vx);      /* float32 position += float64 velocity */
     oy = (float)((double)oy + vy);
@@ -654,50 +701,42 @@ __device__ inline void own_update(const UamParams& p, int e, EnvShare* sh)
     /* dist(drone, goal): float32 - float64 -> float64 with the BLAS ddot FMA form */
     const double dx = (double)ox - gx, dy = (double)oy - gy;
     const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
-    const bool hit = dg < p.goal_r;
-    sh->own_x = ox; sh->own_y = oy;
-    sh->goal_hit = hit ? 1u : 0u;
-    sh->rew_tail = hit ? (float)p.goal_rew : (p.sparse_reward ? (float)p.step_pen : (float)(-dg / p.dense_div));
-    obs_tail(p, ox, oy, vx, vy, sp, hd, gx, gy, sh->tail);
+    const bool hit = dg < p.c->goal_r;
+    const float rew = hit ? (float)p.c->goal_rew : (p.sparse_reward ? (float)p.c->step_pen : (float)(-dg / p.c->dense_div));
+    float t[8];
+    obs_tail(p, ox, oy, vx, vy, sp, hd, gx, gy, t);
+    float4* sh = p.s.share + (size_t)e * 3;
+    sh[0] = make_float4(ox, oy, rew, __uint_as_float(hit ? 1u : 0u));
+    sh[1] = make_float4(t[0], t[1], t[2], t[3]);
+    sh[2] = make_float4(t[4], t[5], t[6], t[7]);
 }
 
-/* ------------------------------------------------------------------ the fused step kernel
- * LDS: [E] EnvShare records, then (aligned obs only) E*D floats of obs staging. */
-template <bool POS64, int RNG, bool RI, bool SH>
-__global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
+/* ------------------------------------------------------------------ launch 2: the intruder sweep
+ * _terminal_reward :146-185 (RandIntruder :181-204), reset_intruder, auto-reset, _get_ob.
+ * LDS (aligned obs only): E*D floats of per-wave obs staging.  No block-level barrier. */
+template <bool POS64, int RNG, bool RI, bool SH, bool ROS>
+__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     typedef typename PosT<POS64>::type P;
+    constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    EnvShare* lds_env = (EnvShare*)lds_raw;
     const int tid = threadIdx.x;
     const int L = p.L;
     const int g = tid >> p.lshift, gl = tid & (L - 1);
     const int env = blockIdx.x * p.E + g;
+    const int wave_first_g = (tid & ~63) >> p.lshift;
+    const int env_first = blockIdx.x * p.E + wave_first_g;
+    if (env_first >= p.B) return;          /* whole wave past the batch end */
     const bool env_ok = env < p.B;
     const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
-    /* prefetch this lane's quad: independent of phase A, overlaps its latency */
     Quad<POS64, SH> q;
     quad_load<POS64, SH>(p, base, quad_ok, q);
+    const float4* shp = p.s.share + (size_t)(env_ok ? env : env_first) * 3;
+    const float4 s0 = shp[0];              /* same address for the whole lane group: one broadcast load */
+    const float ox = s0.x, oy = s0.y;
 
-    /* ---- phase A: ownship kinematics + env-level reward tail, one thread per env */
-    if (tid < p.E) {
-        const int e = blockIdx.x * p.E + tid;
-        if (e < p.B) own_update<RNG>(p, e, &lds_env[tid]);
-    }
-    __syncthreads();
-    if (UAM_ABLATE & 8) return;
-
-    /* a whole wave past the batch end has nothing to do (no barrier follows) */
-    const int wave_first_g = (tid & ~63) >> p.lshift;
-    const int env_first = blockIdx.x * p.E + wave_first_g;
-    if (env_first >= p.B) return;
-
-    const EnvShare& sh = lds_env[env_ok ? g : 0];
-    const float ox = sh.own_x, oy = sh.own_y;
-
-    /* ---- phase B: intruder sweep, _terminal_reward :146-168 (RandIntruder :181-204) */
     P nx[4], ny[4];
     uint32_t confm = 0, oobm = 0, validm = 0;
     uint32_t first_nmac = 0xFFFFu;
@@ -721,12 +760,11 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
         }
         bool conf, nm;
         dist_flags<POS64>(ox, oy, nx[j], ny[j], prom, p, conf, nm);
-        if (valid) {
-            validm |= 1u << j;
-            if (conf) confm |= 1u << j;
-            if (oob) oobm |= 1u << j;
-            if (nm && first_nmac == 0xFFFFu) first_nmac = idx;
-        }
+        /* branch-free: padding lanes/slots are masked out, not skipped */
+        validm |= (valid ? 1u : 0u) << j;
+        confm |= ((valid && conf) ? 1u : 0u) << j;
+        oobm |= ((valid && oob) ? 1u : 0u) << j;
+        first_nmac = (valid && nm && first_nmac == 0xFFFFu) ? idx : first_nmac;
     }
     /* first NMAC index of the env: everything after it is untouched this step (:167-168) */
     const uint32_t kmin = grp_min(first_nmac, L);
@@ -760,7 +798,7 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG>(p, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN>(p, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true;
         }
@@ -773,7 +811,7 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
             if (nxt == 0xFFFFu) break;
             if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             if (mine == nxt) {
                 resp &= ~(1u << (nxt & 3u));
                 q.set((int)(nxt & 3u), X, Y, prom, vx, vy, sp, hd);
@@ -783,13 +821,14 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
     }
 
     /* ---- reward / done / info, :167-185 */
+    const bool goal_hit = __float_as_uint(s0.w) != 0u;
     bool done;
     uint32_t info;
     float reward;
-    if (nmac_any) { reward = (float)p.nmac_pen; done = true; info = UAM_INFO_NMAC; }
-    else if (conf_any) { reward = (float)p.conf_pen; done = false; info = UAM_INFO_CONFLICT; }
-    else if (sh.goal_hit) { reward = sh.rew_tail; done = true; info = UAM_INFO_GOAL; }
-    else { reward = sh.rew_tail; done = false; info = UAM_INFO_NONE; }
+    if (nmac_any) { reward = p.nmac_pen32; done = true; info = UAM_INFO_NMAC; }
+    else if (conf_any) { reward = p.conf_pen32; done = false; info = UAM_INFO_CONFLICT; }
+    else if (goal_hit) { reward = s0.z; done = true; info = UAM_INFO_GOAL; }
+    else { reward = s0.z; done = false; info = UAM_INFO_NONE; }
 
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
@@ -803,8 +842,8 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int j = 2 * m + h;
-                        if (4u * gl + j < (uint32_t)p.N && uam_u32d(w[2 * h]) < p.hc_prob) {
-                            const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * uam_u32d(w[2 * h + 1]);
+                        if (4u * gl + j < (uint32_t)p.N && uam_u32d(w[2 * h]) < p.c->hc_prob) {
+                            const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * uam_u32d(w[2 * h + 1]);
                             q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
                             double sn, cs;
                             uam_sincos(q.hd[SH ? j : 0], &sn, &cs);
@@ -819,10 +858,10 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
             if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             for (int i = 0; i < p.N; i++) {
                 const double pr = 0.0 + 1.0 * mt_double(rng.m);
-                if (pr < p.hc_prob) {
+                if (pr < p.c->hc_prob) {
                     const double ud = mt_double(rng.m);
                     if ((i >> 2) == gl) {
-                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                        const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * ud;
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             if ((i & 3) == j) {
@@ -847,14 +886,20 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
         if (!(done && p.auto_reset) && new_conf) p.s.no_conflict[env] += (int32_t)new_conf;
     }
 
+    /* ownship/goal part of the obs: lanes 0 and 1 of the group carry one float4 each */
+    const int second = L > 1 ? 1 : 0;
     float tail[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) tail[k] = sh.tail[k];
+    {
+        const float4 t0 = (gl == 0) ? shp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t1 = (gl == second || !p.obs_vec) ? shp[2] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tail[0] = t0.x; tail[1] = t0.y; tail[2] = t0.z; tail[3] = t0.w;
+        tail[4] = t1.x; tail[5] = t1.y; tail[6] = t1.z; tail[7] = t1.w;
+    }
 
     /* ---- VecEnv auto-reset: the obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        reset_env<POS64, RNG, SH>(p, env, gl, quad_ok, rng, q, tail);
+        reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail);
         vel_dirty = true;
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
@@ -866,13 +911,13 @@ __global__ void UAM_STEP_BOUNDS uam_step_kernel(const UamParams p)
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (p.obs && !(UAM_ABLATE & 2)) {
-        float* stage = (float*)(lds_raw + (size_t)p.E * sizeof(EnvShare)) + (size_t)wave_first_g * p.D;
+        float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
         obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
     }
 }
 
 /* reset kernel: uam_reset (all envs or mask).  LDS: E*D floats of obs staging (aligned obs only). */
-template <bool POS64, int RNG, bool SH>
+template <bool POS64, int RNG, bool SH, bool ROS>
 __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -893,7 +938,7 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParam
         Rng<RNG> rng;
         rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         rng.load(p.s, env);
-        reset_env<POS64, RNG, SH>(p, env, gl, quad_ok, rng, q, tail);
+        reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail);
         if (gl == 0) rng.store(p.s, env);
         if (quad_ok) {
             quad_store_pos<POS64, SH>(p, base, q);
@@ -966,9 +1011,9 @@ __global__ void uam_policy_kernel(const UamParams p)
         const double bearing = atan2(p.s.goal_y[e] - (double)p.s.own_y[e], p.s.goal_x[e] - (double)p.s.own_x[e]);
         double diff = bearing - p.s.own_h[e];
         diff = diff - UAM_TWO_PI * floor((diff + 0.5 * UAM_TWO_PI) / UAM_TWO_PI);
-        a0 = diff > 0.5 * p.d_heading ? 2 : (diff < -0.5 * p.d_heading ? 0 : 1);
+        a0 = diff > 0.5 * p.c->d_heading ? 2 : (diff < -0.5 * p.c->d_heading ? 0 : 1);
         a1 = 2;
-        ac = (float)fmax(-1.0, fmin(1.0, 1.0 + diff / p.d_heading));
+        ac = (float)fmax(-1.0, fmin(1.0, 1.0 + diff / p.c->d_heading));
     }
     if (p.action_mode == UAM_ACT_DISCRETE9) ((int32_t*)p.actions_out)[e] = a0 * 3 + a1;
     else if (p.action_mode == UAM_ACT_PAIR) ((int2*)p.actions_out)[e] = make_int2(a0, a1);

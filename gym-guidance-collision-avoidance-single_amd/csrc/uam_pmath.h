@@ -121,4 +121,36 @@ UAM_HD double uam_log(double x)
     return ke * LN2_HI - ((hfsq - (t + ke * LN2_LO)) - f);
 }
 
+/* sin and cos of the angle 2*pi*w/2^32 in float32, built from the integer: the top two bits pick
+ * the quadrant exactly, 24 further bits give the position t in [0,1) inside it, and the octant is
+ * folded so the Taylor kernels only see x in [0, pi/4].  |error| < 1.5e-7.  Used for the heading of
+ * freshly spawned intruders in the float32 Philox mode (explicit fmaf: bit-identical host/device). */
+UAM_HD void uam_sincos_turn_f32(uint32_t w, float* sn, float* cs)
+{
+    const uint32_t quad = w >> 30;
+    float t = (float)((w >> 6) & 0xFFFFFFu) * 0x1p-24f;
+    const int fold = t > 0.5f;
+    if (fold) t = 1.0f - t;
+    const float x = 0x1.921fb6p+0f * t;
+    const float z = x * x;
+    float ps = 0x1.71de3ap-19f;
+    ps = __builtin_fmaf(ps, z, -0x1.a01a02p-13f);
+    ps = __builtin_fmaf(ps, z, 0x1.111112p-7f);
+    ps = __builtin_fmaf(ps, z, -0x1.555556p-3f);
+    const float s = __builtin_fmaf(x * z, ps, x);
+    float pc = -0x1.27e4fcp-22f;
+    pc = __builtin_fmaf(pc, z, 0x1.a01a02p-16f);
+    pc = __builtin_fmaf(pc, z, -0x1.6c16c2p-10f);
+    pc = __builtin_fmaf(pc, z, 0x1.555556p-5f);
+    pc = __builtin_fmaf(pc, z, -0.5f);
+    const float c = __builtin_fmaf(z, pc, 1.0f);
+    const float qs = fold ? c : s, qc = fold ? s : c;   /* sin, cos of the in-quadrant angle */
+    float rs = (quad & 1u) ? qc : qs;
+    float rc = (quad & 1u) ? qs : qc;
+    if (quad == 1u || quad == 2u) rc = -rc;
+    if (quad >= 2u) rs = -rs;
+    *sn = rs;
+    *cs = rc;
+}
+
 #endif /* UAM_PMATH_H */

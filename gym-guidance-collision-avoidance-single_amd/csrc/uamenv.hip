@@ -42,6 +42,7 @@ struct uam_env {
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
     uint32_t noise_base;        /* step index of noise row 0 */
     bool noise_valid;
+    UamCold* cold;              /* device copy of the cold configuration */
     UamDev s;
     std::vector<void*> allocs;
     hipEvent_t ev0, ev1;
@@ -123,38 +124,85 @@ static int dev_alloc(uam_env* e, T** out, size_t count)
     return UAM_OK;
 }
 
+/* min{v >= 0 : sqrt(v) >= thr}: `sqrt(d2) < thr`  <=>  `d2 < T2` exactly (sqrt is monotonic and correctly
+ * rounded on host and device alike).  Positive IEEE values order like their bit patterns: bisect on bits. */
+static float sq_threshold_f32(float thr)
+{
+    if (!(thr > 0.0f)) return 0.0f;
+    uint32_t lo = 0, hi = 0x7f800000u;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        float v;
+        memcpy(&v, &mid, 4);
+        if (sqrtf(v) >= thr) hi = mid; else lo = mid + 1;
+    }
+    float r;
+    memcpy(&r, &lo, 4);
+    return r;
+}
+
+static double sq_threshold_f64(double thr)
+{
+    if (!(thr > 0.0)) return 0.0;
+    uint64_t lo = 0, hi = 0x7ff0000000000000ull;
+    while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        double v;
+        memcpy(&v, &mid, 8);
+        if (sqrt(v) >= thr) hi = mid; else lo = mid + 1;
+    }
+    double r;
+    memcpy(&r, &lo, 8);
+    return r;
+}
+
+static void fill_cold(const uam_config& c, UamCold* k)
+{
+    memset(k, 0, sizeof(*k));
+    k->W = c.window_width; k->H = c.window_height; k->min_sep = c.minimum_separation; k->nmac = c.nmac_dist;
+    k->init_min = c.initial_min_dist; k->goal_r = c.goal_radius; k->min_speed = c.min_speed; k->max_speed = c.max_speed;
+    k->d_speed = c.d_speed; k->speed_sigma = c.speed_sigma; k->d_heading = c.d_heading; k->heading_sigma = c.heading_sigma;
+    k->nmac_pen = c.nmac_penalty; k->conf_pen = c.conflict_penalty; k->step_pen = c.step_penalty;
+    k->goal_rew = c.goal_reward; k->dense_div = c.dense_reward_div;
+    k->own_x0 = c.own_x0; k->own_y0 = c.own_y0; k->own_speed0 = c.own_speed0; k->own_heading0 = c.own_heading0;
+    k->hc_prob = c.heading_change_prob; k->hc_max_deg = c.heading_change_max_deg;
+    k->inv_2vmax = 1.0 / (c.max_speed * 2); k->inv_vrange = 1.0 / (c.max_speed - c.min_speed);
+    k->inv_W = 1.0 / c.window_width; k->inv_H = 1.0 / c.window_height;
+    double sn, cs;
+    uam_sincos(c.own_heading0, &sn, &cs);       /* Aircraft.__init__ float32 velocity, :275-277 */
+    k->own_vx0 = (double)(float)(c.own_speed0 * cs); k->own_vy0 = (double)(float)(c.own_speed0 * sn);
+    k->sep2 = sq_threshold_f64(c.minimum_separation); k->nmac2 = sq_threshold_f64(c.nmac_dist);
+    k->init2 = sq_threshold_f64(c.initial_min_dist);
+}
+
 static void fill_params(const uam_env* e, UamParams* p)
 {
     const uam_config& c = e->cfg;
     memset(p, 0, sizeof(*p));
     p->s = e->s;
+    p->c = e->cold;
     p->B = c.num_envs; p->N = c.num_intruders; p->Np = e->Np; p->Q = e->Q; p->L = e->L; p->lshift = e->lshift;
     p->E = e->E; p->D = e->D;
     p->obs_mode = c.obs_mode; p->action_mode = c.action_mode; p->auto_reset = c.auto_reset;
-    p->sparse_reward = c.sparse_reward; p->random_own_start = c.random_own_start;
+    p->sparse_reward = c.sparse_reward;
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
-    p->hold_sh = e->hold_sh;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
-    p->W = c.window_width; p->H = c.window_height; p->min_sep = c.minimum_separation; p->nmac = c.nmac_dist;
-    p->init_min = c.initial_min_dist; p->goal_r = c.goal_radius; p->min_speed = c.min_speed; p->max_speed = c.max_speed;
-    p->d_speed = c.d_speed; p->speed_sigma = c.speed_sigma; p->d_heading = c.d_heading; p->heading_sigma = c.heading_sigma;
-    p->nmac_pen = c.nmac_penalty; p->conf_pen = c.conflict_penalty; p->step_pen = c.step_penalty;
-    p->goal_rew = c.goal_reward; p->dense_div = c.dense_reward_div;
-    p->own_x0 = c.own_x0; p->own_y0 = c.own_y0; p->own_speed0 = c.own_speed0; p->own_heading0 = c.own_heading0;
-    p->hc_prob = c.heading_change_prob; p->hc_max_deg = c.heading_change_max_deg;
-    p->W32 = (float)c.window_width; p->H32 = (float)c.window_height;
-    p->vmax32 = (float)c.max_speed; p->vden32 = (float)(c.max_speed * 2);
-    p->psig32 = (float)c.position_sigma;
-    p->min_sep32 = (float)c.minimum_separation; p->nmac32 = (float)c.nmac_dist; p->init_min32 = (float)c.initial_min_dist;
-    p->inv_2vmax = 1.0 / (c.max_speed * 2); p->inv_vrange = 1.0 / (c.max_speed - c.min_speed);
-    p->inv_W = 1.0 / c.window_width; p->inv_H = 1.0 / c.window_height;
     p->step_index = e->step_index;
+    p->W32 = (float)c.window_width; p->H32 = (float)c.window_height;
+    p->vmax32 = (float)c.max_speed; p->psig32 = (float)c.position_sigma;
+    /* NEP-50: a float32 distance compares against float32(threshold) */
+    p->sep2_32 = sq_threshold_f32((float)c.minimum_separation); p->nmac2_32 = sq_threshold_f32((float)c.nmac_dist);
+    p->init2_32 = sq_threshold_f32((float)c.initial_min_dist);
+    p->inv_W32 = 1.0f / (float)c.window_width; p->inv_H32 = 1.0f / (float)c.window_height;
+    p->inv_vden32 = 1.0f / (float)(c.max_speed * 2);
+    p->nmac_pen32 = (float)c.nmac_penalty; p->conf_pen32 = (float)c.conflict_penalty;
+    p->spawn_sx = (float)c.window_width * 0x1p-24f; p->spawn_sy = (float)c.window_height * 0x1p-24f;
+    p->min_speed32 = (float)c.min_speed; p->vrange32 = (float)(c.max_speed - c.min_speed);
 }
 
 static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
 static inline size_t lds_stage(const uam_env* e, const UamParams& p) { return p.obs_vec ? (size_t)e->E * e->D * 4 : 0; }
-static inline size_t lds_step(const uam_env* e, const UamParams& p) { return (size_t)e->E * sizeof(EnvShare) + lds_stage(e, p); }
 
 extern "C" int uam_seed(uam_env* e, const uint64_t* seeds);
 
@@ -190,9 +238,9 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     while (L < e->Q) { L <<= 1; ls++; }
     e->L = L; e->lshift = ls;
     /* block size: as large as 512 while the grid still has >= 1024 blocks (4 per CU), never below a wave */
-    int T = UAM_MAX_BLOCK;
+    int T = 256;
     if (const char* tb = getenv("UAMENV_BLOCK")) T = atoi(tb);   /* development override */
-    if (T > UAM_MAX_BLOCK || T < 64 || (T & (T - 1))) T = UAM_MAX_BLOCK;
+    if (T > UAM_MAX_BLOCK || T < 64 || (T & (T - 1))) T = 256;
     while (T > 64 && T > L && ((int64_t)B * L + T - 1) / T < 1024) T >>= 1;
     if (T < L) T = L;
     if (T < 64) T = 64;
@@ -232,6 +280,14 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (!rc) rc = dev_alloc(e, &e->s.goal_y, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.reset_count, (size_t)B);
+    if (!rc) rc = dev_alloc(e, &e->s.share, (size_t)B * 3);
+    e->cold = nullptr;
+    if (!rc) rc = dev_alloc(e, &e->cold, (size_t)1);
+    if (!rc) {
+        UamCold hk;
+        fill_cold(*cfg, &hk);
+        if (hipMemcpy(e->cold, &hk, sizeof(hk), hipMemcpyHostToDevice) != hipSuccess) rc = fail(UAM_EIO, "hipMemcpy(cold config) failed");
+    }
     if (cfg->rng_mode == UAM_RNG_PHILOX && !rc) rc = dev_alloc(e, &e->noise, (size_t)B * NOISE_AHEAD);
     if (cfg->rng_mode == UAM_RNG_MT19937) {
         if (!rc) rc = dev_alloc(e, &e->s.mt_key, (size_t)B * UAM_MT_N);
@@ -303,45 +359,53 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
     return UAM_OK;
 }
 
-/* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held) ---- */
-template <bool POS64, int RNG>
-static void launch_step_t(const uam_env* e, const UamParams& p, hipStream_t st)
-{
-    dim3 grid(grid_of(e)), block(e->T);
-    const size_t lds = lds_step(e, p);
-    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER)
-        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, true, true>), grid, block, lds, st, p);
-    else if (e->hold_sh)
-        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false, true>), grid, block, lds, st, p);
-    else
-        hipLaunchKernelGGL((uam_step_kernel<POS64, RNG, false, false>), grid, block, lds, st, p);
-}
-
-static void launch_step(const uam_env* e, const UamParams& p, hipStream_t st)
-{
-    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
-    if (x && mt) launch_step_t<true, UAM_RNG_MT19937>(e, p, st);
-    else if (x) launch_step_t<true, UAM_RNG_PHILOX>(e, p, st);
-    else if (mt) launch_step_t<false, UAM_RNG_MT19937>(e, p, st);
-    else launch_step_t<false, UAM_RNG_PHILOX>(e, p, st);
-}
-
-template <bool POS64, int RNG>
-static void launch_reset_t(const uam_env* e, const UamParams& p, hipStream_t st)
+/* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held, random ownship start) ---- */
+template <bool POS64, int RNG, bool RI, bool SH>
+static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t st)
 {
     dim3 grid(grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
-    if (e->hold_sh) hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, false>), grid, block, lds, st, p);
+    if (e->cfg.random_own_start) hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false>), grid, block, lds, st, p);
+}
+
+template <bool POS64, int RNG>
+static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, true, true>(e, p, st);
+    else if (e->hold_sh) launch_sweep_ros<POS64, RNG, false, true>(e, p, st);
+    else launch_sweep_ros<POS64, RNG, false, false>(e, p, st);
+}
+
+/* one env.step(): ownship kernel (thread per env) then the intruder sweep (lane group per env) */
+static void launch_step(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
+    dim3 ogrid((e->cfg.num_envs + 63) / 64), oblock(64);
+    if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p);
+    else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p);
+    if (x && mt) launch_sweep_t<true, UAM_RNG_MT19937>(e, p, st);
+    else if (x) launch_sweep_t<true, UAM_RNG_PHILOX>(e, p, st);
+    else if (mt) launch_sweep_t<false, UAM_RNG_MT19937>(e, p, st);
+    else launch_sweep_t<false, UAM_RNG_PHILOX>(e, p, st);
+}
+
+template <bool POS64, int RNG, bool SH>
+static void launch_reset_ros(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    const size_t lds = lds_stage(e, p);
+    if (e->cfg.random_own_start) hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, SH, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, SH, false>), grid, block, lds, st, p);
 }
 
 static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
 {
-    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
-    if (x && mt) launch_reset_t<true, UAM_RNG_MT19937>(e, p, st);
-    else if (x) launch_reset_t<true, UAM_RNG_PHILOX>(e, p, st);
-    else if (mt) launch_reset_t<false, UAM_RNG_MT19937>(e, p, st);
-    else launch_reset_t<false, UAM_RNG_PHILOX>(e, p, st);
+    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937, sh = e->hold_sh != 0;
+    if (x && mt) { if (sh) launch_reset_ros<true, UAM_RNG_MT19937, true>(e, p, st); else launch_reset_ros<true, UAM_RNG_MT19937, false>(e, p, st); }
+    else if (x) { if (sh) launch_reset_ros<true, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<true, UAM_RNG_PHILOX, false>(e, p, st); }
+    else if (mt) { if (sh) launch_reset_ros<false, UAM_RNG_MT19937, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_MT19937, false>(e, p, st); }
+    else { if (sh) launch_reset_ros<false, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_PHILOX, false>(e, p, st); }
 }
 
 static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)

@@ -212,7 +212,7 @@ class BatchedSingleAircraftEnv:
         if self._pending is None:
             raise RuntimeError("not running an async step")
         self._pending = None
-        return self._obs, self._rew, self._done.bool(), LazyInfos(self._info)
+        return self._obs, self._rew, self._done.view(self._torch.bool), LazyInfos(self._info)   # 0/1 bytes: zero-copy view
 
     def step(self, actions):
         self.step_async(actions)

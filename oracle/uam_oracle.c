@@ -227,6 +227,36 @@ static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t*
     env_t* e = c->e;
     double px, py, speed, heading;
     uint32_t w[4];
+    /* float32 Philox mode with no stored speed/heading ("lean"): the whole spawn is float32
+     * arithmetic on the Philox words; restated here independently of csrc/uam_device.h */
+    const int hold_sh = g->dynamics == UAM_DYN_RANDINTRUDER || g->obs_mode == UAM_OBS_RAW6;
+    if (g->rng_mode == UAM_RNG_PHILOX && g->precision == UAM_POS_F32 && !hold_sh) {
+        const uint32_t purpose = reset_phase ? PH_RESET_SPAWN : PH_SPAWN;
+        const float sx = (float)g->window_width * 0x1p-24f, sy = (float)g->window_height * 0x1p-24f;
+        philox(c, purpose, (uint32_t)idx, 0, w);
+        float fx = (float)(w[0] >> 8) * sx, fy = (float)(w[1] >> 8) * sy;
+        const float u = (float)(w[2] >> 8) * 0x1p-24f;
+        const float prod = (float)((float)(g->max_speed - g->min_speed) * u);
+        const float spf = (float)((float)g->min_speed + prod);
+        float sn, cs;
+        uam_sincos_turn_f32(w[3], &sn, &cs);
+        out->vx = (float)(spf * cs);
+        out->vy = (float)(spf * sn);
+        out->speed = 0.0; out->heading = 0.0;
+        out->promoted = 0;
+        out->conflict = 0;
+        out->x = (double)fx; out->y = (double)fy;
+        e->spawns++;
+        uint32_t attempt = 0;
+        while (dist_lt(out, dist_own_intruder(e, out), g->initial_min_dist)) {
+            attempt++;
+            philox(c, purpose, (uint32_t)idx, attempt, w);
+            out->x = (double)((float)(w[0] >> 8) * sx);
+            out->y = (double)((float)(w[1] >> 8) * sy);
+            e->redraws++;
+        }
+        return;
+    }
     if (g->rng_mode == UAM_RNG_MT19937) {
         px = 0.0 + g->window_width * mt_double(e->mt);
         py = 0.0 + g->window_height * mt_double(e->mt);
