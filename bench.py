@@ -9,9 +9,15 @@ state, action tape) are resident in HBM before the timed region; observations, r
 stay on the device.  With N>1 every rank owns 65536 envs (weak scaling, env_id_offset = rank*B so
 the union is one consistent batch) and the per-chunk reward/done slabs are all-gathered with RCCL.
 
+One step is two dependent launches (uam_own_kernel: fp64 ownship kinematics, one thread per env;
+uam_sweep_kernel: the intruder sweep / reduction / respawn / obs pack, one lane group per env).
+
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : algorithmic HBM bytes per launch / average launch duration (hipEvents on the
-                 launch stream) against the 8 TB/s HBM3E peak,
+  roofline     : for the dominant kernel (uam_sweep_kernel): algorithmic HBM bytes per launch
+                 (SURVEY §8d accounting) / its average launch duration, measured live
+                 with hipEvents bracketing that kernel on the launch stream in a separate 256-step pass
+                 after the timed region, against the 8 TB/s HBM3E peak.  `traffic` is the PMC figure
+                 (FETCH_SIZE x2 + WRITE_SIZE per launch) committed under profiles/, when present,
   cpu_baseline : the CPU oracle (a port of the reference's step()) timed on this host's cores on a
                  bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -136,11 +142,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # per-kernel durations: a separate pass with hipEvents around each launch (not part of `value`)
+    env.kernel_timing(True)
+    run(256, offset=args.warmup + args.steps)
+    own_ms, sweep_ms, nsamp = env.kernel_timing_read()
+    env.kernel_timing(False)
+
     if rank == 0:
         total_env_steps = float(B) * world * args.steps
         value = total_env_steps / elapsed
-        step_bytes = env.step_bytes
-        achieved = step_bytes / (kernel_ms * 1e-3) / 1e9
+        step_bytes = env.step_bytes                      # (40 N + 150) B per env-step, SURVEY §8d
+        own_bytes = 88 * B                               # ownship/goal/action/counter share of the 150 B
+        sweep_bytes = step_bytes - own_bytes             # (40 N + 62) B per env: what uam_sweep_kernel must move
+        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc_path) and B == B_PER_GPU and N == N_INTRUDERS:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get("uam_sweep_kernel", {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -153,9 +172,12 @@ def main():
                        "exchange": "none" if world == 1 else "all_gather(reward,done) every %d steps" % GATHER_EVERY},
             "pair_steps_per_sec": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "uam_step_kernel<f32,philox,straight>", "bytes_per_launch": step_bytes,
-                         "avg_launch_ms": kernel_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "uam_sweep_kernel<f32,philox,straight>", "bytes_per_launch": sweep_bytes,
+                         "avg_launch_ms": sweep_ms, "sampled_launches": nsamp,
+                         "own_kernel_avg_ms": own_ms,
+                         "whole_step": {"bytes": step_bytes, "avg_ms": kernel_ms,
+                                        "frac": step_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -10,9 +10,10 @@ from ._capi import UamError, build, default_config
 from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2Env, SingleAircraftEnv,
                    SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv, make_config)
 from . import spaces
+from .sharded import ShardedSingleAircraftEnv, shard_bounds
 
 __all__ = [
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
     "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv", "make_config",
-    "UamError", "build", "default_config", "spaces",
+    "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds",
 ]

@@ -97,6 +97,8 @@ SYMBOLS = [
     ("uam_step_bytes", C.c_int64, [_P]),
     ("uam_timing_begin", C.c_int, [_P, _P]),
     ("uam_timing_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    ("uam_kernel_timing", C.c_int, [_P, C.c_int32]),
+    ("uam_kernel_timing_read", C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     ("uam_last_error", C.c_char_p, []),
     ("uam_version", C.c_char_p, []),
 ]

@@ -38,8 +38,13 @@
 #define UAM_MT_N 624
 #define UAM_MT_M 397
 #define UAM_MAX_BLOCK 512
-#ifndef UAM_STEP_WAVES_PER_EU
-#define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK)
+/* <= 80 SGPRs: above that gfx950 admits only 6 (97..112: 6, 81..96: 7) 256-thread blocks per CU instead
+ * of 8 (MI355X_MICROARCH.md, residency), which costs the sweep a second, thinly occupied round of blocks */
+#ifndef UAM_SGPR_CAP
+#define UAM_SGPR_CAP 80
+#endif
+#if !defined(UAM_STEP_WAVES_PER_EU)
+#define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_num_sgpr(UAM_SGPR_CAP)))
 #else
 #define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_STEP_WAVES_PER_EU, 8)))
 #endif
@@ -655,25 +660,25 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
  * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
  * one thread per env. */
 template <int RNG>
-__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p)
+__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const UamCold c)
 {
+    /* the cold configuration arrives BY VALUE here (kernarg, scalar loads, no aliasing with the stores
+     * below); every input is loaded up front so the kernel pays one memory round trip, not five */
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.B) return;
-    float ox = p.s.own_x[e], oy = p.s.own_y[e];
-    double hd = p.s.own_h[e], sp = p.s.own_s[e];
+    float* __restrict__ own_x = p.s.own_x; float* __restrict__ own_y = p.s.own_y;
+    double* __restrict__ own_h = p.s.own_h; double* __restrict__ own_s = p.s.own_s;
+    float ox = own_x[e], oy = own_y[e];
+    double hd = own_h[e], sp = own_s[e];
     const double gx = p.s.goal_x[e], gy = p.s.goal_y[e];
-    double a0 = 1.0, a1 = 1.0;
-    bool has_speed = true;
-    if (p.action_mode == UAM_ACT_DISCRETE9) {
-        int a = ((const int32_t*)p.actions)[e];
-        a0 = (double)(a / 3); a1 = (double)(a % 3);          /* :128-131 */
-    } else if (p.action_mode == UAM_ACT_PAIR) {
-        int2 a = ((const int2*)p.actions)[e];
-        a0 = (double)a.x; a1 = (double)a.y;
-    } else {
-        a0 = (double)((const float*)p.actions)[e];
-        has_speed = false;
-    }
+    /* branch-free action fetch: two 32-bit words whatever the encoding (the second aliases the first
+     * unless the action is a pair), decoded after all loads are in flight */
+    const bool is_pair = p.action_mode == UAM_ACT_PAIR;
+    const uint32_t* __restrict__ aw = (const uint32_t*)p.actions;
+    const size_t i0 = is_pair ? 2 * (size_t)e : (size_t)e;
+    const uint32_t w0 = aw[i0], w1 = aw[is_pair ? i0 + 1 : i0];
+    const int ai0 = (int)w0, ai1 = (int)w1;
+    const float af = __uint_as_float(w0);
     double zh, zs;
     if constexpr (RNG == UAM_RNG_PHILOX) {
         const double2 z = p.noise[e];   /* drawn ahead by uam_noise_kernel */
@@ -685,27 +690,44 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p)
         zs = mt_gauss(rng.m);
         rng.store(p.s, e);
     }
-    hd += p.c->d_heading * (a0 - 1.0);
-    hd += 0.0 + p.c->heading_sigma * zh;
-    if (has_speed) sp += p.c->d_speed * (a1 - 1.0);
-    sp = fmax(p.c->min_speed, fmin(sp, p.c->max_speed));
-    sp += 0.0 + p.c->speed_sigma * zs;
+    double a0, a1;
+    bool has_speed = true;
+    if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
+    else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
+    else { a0 = (double)af; a1 = 1.0; has_speed = false; }
+    hd += c.d_heading * (a0 - 1.0);
+    hd += 0.0 + c.heading_sigma * zh;
+    if (has_speed) sp += c.d_speed * (a1 - 1.0);
+    sp = fmax(c.min_speed, fmin(sp, c.max_speed));
+    sp += 0.0 + c.speed_sigma * zs;
     double sn, cs;
     uam_sincos(hd, &sn, &cs);
     const double vx = sp * cs, vy = sp * sn;
     ox = (float)((double)ox + vx);      /* float32 position += float64 velocity */
     oy = (float)((double)oy + vy);
-    p.s.own_x[e] = ox; p.s.own_y[e] = oy;
-    p.s.own_h[e] = hd; p.s.own_s[e] = sp;
-    p.s.own_vx[e] = vx; p.s.own_vy[e] = vy;
     /* dist(drone, goal): float32 - float64 -> float64 with the BLAS ddot FMA form */
     const double dx = (double)ox - gx, dy = (double)oy - gy;
     const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
-    const bool hit = dg < p.c->goal_r;
-    const float rew = hit ? (float)p.c->goal_rew : (p.sparse_reward ? (float)p.c->step_pen : (float)(-dg / p.c->dense_div));
+    const bool hit = dg < c.goal_r;
+    const float rew = hit ? (float)c.goal_rew : (p.sparse_reward ? (float)c.step_pen : (float)(-dg / c.dense_div));
     float t[8];
-    obs_tail(p, ox, oy, vx, vy, sp, hd, gx, gy, t);
-    float4* sh = p.s.share + (size_t)e * 3;
+    if (p.obs_mode == UAM_OBS_NORM4) {
+        t[0] = ox * p.inv_W32;
+        t[1] = oy * p.inv_H32;
+        t[2] = (float)((vx + c.max_speed) * c.inv_2vmax);
+        t[3] = (float)((vy + c.max_speed) * c.inv_2vmax);
+        t[4] = (float)((sp - c.min_speed) * c.inv_vrange);
+        t[5] = (float)(hd * (1.0 / UAM_TWO_PI));
+        t[6] = (float)(gx * c.inv_W);
+        t[7] = (float)(gy * c.inv_H);
+    } else {
+        t[0] = ox; t[1] = oy; t[2] = (float)vx; t[3] = (float)vy;
+        t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
+    }
+    own_x[e] = ox; own_y[e] = oy;
+    own_h[e] = hd; own_s[e] = sp;
+    p.s.own_vx[e] = vx; p.s.own_vy[e] = vy;
+    float4* __restrict__ sh = p.s.share + (size_t)e * 3;
     sh[0] = make_float4(ox, oy, rew, __uint_as_float(hit ? 1u : 0u));
     sh[1] = make_float4(t[0], t[1], t[2], t[3]);
     sh[2] = make_float4(t[4], t[5], t[6], t[7]);

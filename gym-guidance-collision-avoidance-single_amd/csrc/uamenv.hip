@@ -42,7 +42,11 @@ struct uam_env {
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
     uint32_t noise_base;        /* step index of noise row 0 */
     bool noise_valid;
+    std::vector<hipEvent_t> kev;  /* 3 events per sampled step (before own, between, after sweep) */
+    bool ktiming;
+    int ksamples;
     UamCold* cold;              /* device copy of the cold configuration */
+    UamCold hcold;              /* host copy, passed by value to the ownship kernel */
     UamDev s;
     std::vector<void*> allocs;
     hipEvent_t ev0, ev1;
@@ -227,6 +231,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->timed_launches = 0;
     e->policy_calls = 0;
     e->step_index = 0;
+    e->ktiming = false;
+    e->ksamples = 0;
     e->noise = nullptr;
     e->noise_base = 0;
     e->noise_valid = false;
@@ -284,9 +290,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->cold = nullptr;
     if (!rc) rc = dev_alloc(e, &e->cold, (size_t)1);
     if (!rc) {
-        UamCold hk;
-        fill_cold(*cfg, &hk);
-        if (hipMemcpy(e->cold, &hk, sizeof(hk), hipMemcpyHostToDevice) != hipSuccess) rc = fail(UAM_EIO, "hipMemcpy(cold config) failed");
+        fill_cold(*cfg, &e->hcold);
+        if (hipMemcpy(e->cold, &e->hcold, sizeof(e->hcold), hipMemcpyHostToDevice) != hipSuccess) rc = fail(UAM_EIO, "hipMemcpy(cold config) failed");
     }
     if (cfg->rng_mode == UAM_RNG_PHILOX && !rc) rc = dev_alloc(e, &e->noise, (size_t)B * NOISE_AHEAD);
     if (cfg->rng_mode == UAM_RNG_MT19937) {
@@ -316,6 +321,7 @@ extern "C" int uam_destroy(uam_env* e)
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : e->kev) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -378,16 +384,23 @@ static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
 }
 
 /* one env.step(): ownship kernel (thread per env) then the intruder sweep (lane group per env) */
-static void launch_step(const uam_env* e, const UamParams& p, hipStream_t st)
+static const int KTIMING_MAX = 256;
+
+static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
 {
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
+    const bool sample = e->ktiming && e->ksamples < KTIMING_MAX;
+    hipEvent_t* ev = sample ? &e->kev[(size_t)3 * e->ksamples] : nullptr;
     dim3 ogrid((e->cfg.num_envs + 63) / 64), oblock(64);
-    if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p);
-    else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p);
+    if (sample) (void)hipEventRecord(ev[0], st);
+    if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p, e->hcold);
+    else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p, e->hcold);
+    if (sample) (void)hipEventRecord(ev[1], st);
     if (x && mt) launch_sweep_t<true, UAM_RNG_MT19937>(e, p, st);
     else if (x) launch_sweep_t<true, UAM_RNG_PHILOX>(e, p, st);
     else if (mt) launch_sweep_t<false, UAM_RNG_MT19937>(e, p, st);
     else launch_sweep_t<false, UAM_RNG_PHILOX>(e, p, st);
+    if (sample) { (void)hipEventRecord(ev[2], st); e->ksamples++; }
 }
 
 template <bool POS64, int RNG, bool SH>
@@ -552,6 +565,38 @@ extern "C" int64_t uam_step_bytes(const uam_env* e)
      * per env: SURVEY §8d's 150 B (ownship, goal, flags, counters, action, obs tail, reward/done/info) */
     const int64_t per_int = 4 * posb + 8 + 4 * obs_w + (e->hold_sh ? 16 : 0);
     return (int64_t)e->cfg.num_envs * (per_int * e->cfg.num_intruders + 150);
+}
+
+extern "C" int uam_kernel_timing(uam_env* e, int32_t enable)
+{
+    if (!e) return fail(UAM_EINVAL, "env is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    if (enable && e->kev.empty()) {
+        e->kev.resize((size_t)3 * KTIMING_MAX, nullptr);
+        for (auto& ev : e->kev) HIP_TRY(hipEventCreate(&ev));
+    }
+    e->ktiming = enable != 0;
+    e->ksamples = 0;
+    return UAM_OK;
+}
+
+extern "C" int uam_kernel_timing_read(uam_env* e, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out)
+{
+    if (!e || !own_ms_out || !sweep_ms_out || !samples_out) return fail(UAM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    double own = 0, sweep = 0;
+    for (int i = 0; i < e->ksamples; i++) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, e->kev[(size_t)3 * i], e->kev[(size_t)3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, e->kev[(size_t)3 * i + 1], e->kev[(size_t)3 * i + 2]));
+        own += a; sweep += b;
+    }
+    *samples_out = e->ksamples;
+    *own_ms_out = e->ksamples ? (float)(own / e->ksamples) : 0.f;
+    *sweep_ms_out = e->ksamples ? (float)(sweep / e->ksamples) : 0.f;
+    e->ksamples = 0;
+    return UAM_OK;
 }
 
 extern "C" int uam_timing_begin(uam_env* e, void* stream)

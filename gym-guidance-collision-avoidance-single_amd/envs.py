@@ -267,6 +267,16 @@ class BatchedSingleAircraftEnv:
         capi.check(self._lib.uam_timing_end(self._h, self._stream(), C.byref(ms)))
         return float(ms.value)
 
+    def kernel_timing(self, enable=True):
+        """Bracket each launch of the following steps with hipEvents (diagnostic; serialises launches)."""
+        capi.check(self._lib.uam_kernel_timing(self._h, int(bool(enable))))
+
+    def kernel_timing_read(self):
+        """-> (ownship-kernel ms, sweep-kernel ms, sampled steps) averaged over the sampled steps."""
+        a, b, n = C.c_float(0), C.c_float(0), C.c_int32(0)
+        capi.check(self._lib.uam_kernel_timing_read(self._h, self._stream(), C.byref(a), C.byref(b), C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)
+
     # ---- state exchange (checkpoint / parity injection)
     def get_state(self, fields=None):
         B, N = self.num_envs, self.intruder_size

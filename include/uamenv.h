@@ -208,6 +208,13 @@ int64_t uam_step_bytes(const uam_env* env);
 int uam_timing_begin(uam_env* env, void* stream);
 int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
 
+/* Per-kernel device times.  While enabled, every uam_step brackets its two launches with hipEvents
+ * (up to 256 steps are sampled; this serialises the launches slightly, so keep it out of throughput
+ * runs).  uam_kernel_timing_read synchronises `stream` and returns the mean duration in milliseconds of
+ * the ownship kernel and of the intruder-sweep kernel over the sampled steps. */
+int uam_kernel_timing(uam_env* env, int32_t enable);
+int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out);
+
 const char* uam_last_error(void);
 const char* uam_version(void);
 
