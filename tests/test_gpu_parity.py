@@ -253,3 +253,80 @@ def test_full_size_invariants_under_random_policy(uamenv):
         env.close()
     assert np.array_equal(runs[0], runs[1]), "two runs from the same seed differ: %s vs %s" % (runs[0], runs[1])
     assert runs[0][1] > 0, "no episode ended in %d steps" % T
+
+
+# ---------------------------------------------------------------- edge shapes and fallback paths
+@pytest.mark.parametrize("B,N,variant", [(1, 1, "discrete9"), (3, 3, "discrete9"), (1, 32, "discrete9"),
+                                         (70, 5, "randintruder"),   # D = 6*5+8 = 38: rows not 16-B aligned -> scalar obs path
+                                         (65, 7, "mcts"), (130, 33, "discrete9")])
+def test_edge_shapes_match_oracle(uamenv, oracle, B, N, variant):
+    pu.run_lockstep(uamenv, oracle, B, N, 150, policy="goal", variant=variant, rng="philox", precision="f32",
+                    check_state_every=10)
+    pu.run_lockstep(uamenv, oracle, B, N, 60, policy="goal", variant=variant, rng="mt19937", precision="exact",
+                    check_state_every=10)
+
+
+def test_unaligned_obs_pointer_uses_the_scalar_path(uamenv, oracle):
+    """obs_out only 4-byte aligned: the library must fall back to per-element stores, same values."""
+    import ctypes as C
+    import torch
+    B, N = 96, 8
+    env = uamenv.BatchedSingleAircraftEnv(B, N, seed=11)
+    ref = env.reset().clone()
+    D = env.obs_dim
+    raw = torch.zeros(B * D + 8, dtype=torch.float32, device=env.device)
+    off = raw[1:1 + B * D]                      # +4 bytes: not 16-byte aligned
+    assert off.data_ptr() % 16 != 0
+    uamenv._capi.check(env._lib.uam_observe(env._h, C.c_void_p(off.data_ptr()), env._stream()))
+    assert torch.equal(off.view(B, D), ref)
+    acts = torch.randint(0, 9, (B,), dtype=torch.int32, device=env.device)
+    st = env.get_state()
+    o1 = env.step(acts)[0].clone()
+    env.set_state(st)
+    uamenv._capi.check(env._lib.uam_step(env._h, C.c_void_p(acts.data_ptr()), C.c_void_p(off.data_ptr()),
+                                         C.c_void_p(env._rew.data_ptr()), C.c_void_p(env._done.data_ptr()),
+                                         C.c_void_p(env._info.data_ptr()), env._stream()))
+    assert torch.equal(off.view(B, D), o1)
+    assert float(raw[0]) == 0.0 and float(raw[1 + B * D]) == 0.0      # no write outside the buffer
+    env.close()
+
+
+def test_mt19937_state_exports_in_numpy_layout(uamenv, oracle):
+    """get_state() finishes the lazily twisted round: key/pos/gauss equal the oracle's NumPy-format state,
+    and importing a NumPy-format state continues the same stream."""
+    B, N = 16, 8
+    env = uamenv.BatchedSingleAircraftEnv(B, N, rng="mt19937", precision="exact", seed=321, auto_reset=True)
+    orc = oracle.OracleBatch(pu.oracle_cfg_from(oracle, env.cfg), oracle.MATH_PORTABLE)
+    env.reset()
+    orc.reset()
+    rs = np.random.RandomState(0)
+    for t in range(140):                          # crosses a 624-word round (about 5 words per step + spawns)
+        a = rs.randint(0, 9, size=B).astype(np.int32)
+        env.step(a)
+        orc.step(a)
+    gs, os_ = env.get_state(), orc.get_state()
+    for k in ("mt_key", "mt_pos", "mt_has_gauss", "mt_gauss"):
+        assert np.array_equal(gs[k], os_[k]), k
+    # round trip through the NumPy layout, then keep stepping in lockstep
+    env.set_state(gs)
+    for t in range(40):
+        a = rs.randint(0, 9, size=B).astype(np.int32)
+        o, r, d, inf = env.step(a)
+        oo = orc.step(a)
+        assert np.array_equal(r.cpu().numpy(), oo[1].astype(np.float32)) and np.array_equal(d.cpu().numpy().astype(np.uint8), oo[2])
+    pu.compare_states(env.get_state(), orc.get_state(), "after numpy-layout round trip")
+    env.close()
+
+
+def test_seed_array_and_reseed(uamenv, oracle):
+    """Per-env seeds: env e of a batch equals a single env seeded the same (MT19937 mode)."""
+    seeds = np.array([5, 99, 5, 12345], dtype=np.uint64)
+    env = uamenv.BatchedSingleAircraftEnv(4, 8, rng="mt19937", precision="exact", auto_reset=False)
+    env.seed(seeds)
+    obs = env.reset().cpu().numpy()
+    assert np.array_equal(obs[0], obs[2]) and not np.array_equal(obs[0], obs[1])
+    fx = gu.load("g2_goalseek_n8_seed3")
+    env.seed(np.array([3, 3, 3, 3], dtype=np.uint64))
+    obs = env.reset().cpu().numpy()
+    assert np.abs(obs[1] - fx["obs0"]).max() <= 1e-5
+    env.close()
