@@ -660,12 +660,10 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
  * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
  * one thread per env. */
 template <int RNG>
-__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const UamCold c)
+__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh)
 {
-    /* the cold configuration arrives BY VALUE here (kernarg, scalar loads, no aliasing with the stores
-     * below); every input is loaded up front so the kernel pays one memory round trip, not five */
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.B) return;
+    /* the cold configuration arrives BY VALUE (kernarg, scalar loads, no aliasing with the stores
+     * below); every input is loaded up front so the thread pays one memory round trip, not five */
     float* __restrict__ own_x = p.s.own_x; float* __restrict__ own_y = p.s.own_y;
     double* __restrict__ own_h = p.s.own_h; double* __restrict__ own_s = p.s.own_s;
     float ox = own_x[e], oy = own_y[e];
@@ -727,17 +725,29 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
     own_x[e] = ox; own_y[e] = oy;
     own_h[e] = hd; own_s[e] = sp;
     p.s.own_vx[e] = vx; p.s.own_vy[e] = vy;
-    float4* __restrict__ sh = p.s.share + (size_t)e * 3;
     sh[0] = make_float4(ox, oy, rew, __uint_as_float(hit ? 1u : 0u));
     sh[1] = make_float4(t[0], t[1], t[2], t[3]);
     sh[2] = make_float4(t[4], t[5], t[6], t[7]);
 }
 
+template <int RNG>
+__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const UamCold c)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.B) return;
+    own_compute<RNG>(p, c, e, p.s.share + (size_t)e * 3);
+}
+
 /* ------------------------------------------------------------------ launch 2: the intruder sweep
  * _terminal_reward :146-185 (RandIntruder :181-204), reset_intruder, auto-reset, _get_ob.
  * LDS (aligned obs only): E*D floats of per-wave obs staging.  No block-level barrier. */
-template <bool POS64, int RNG, bool RI, bool SH, bool ROS>
-__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
+/* FUSED: the ownship phase runs inside this launch — the first E threads of the block compute the
+ * block's E envs (one thread per env) while the other waves already have their quad loads in flight,
+ * hand the 48-byte records over through LDS, and one block barrier later everyone sweeps.  Saves the
+ * separate launch (5.5 us of pure latency at B=65536); only worth it where the fp64 phase fits the
+ * sweep's register budget (the lean float32/Philox configuration). */
+template <bool POS64, int RNG, bool RI, bool SH, bool ROS, bool FUSED>
+__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p, const UamCold cv)
 {
     typedef typename PosT<POS64>::type P;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
@@ -748,14 +758,31 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     const int env = blockIdx.x * p.E + g;
     const int wave_first_g = (tid & ~63) >> p.lshift;
     const int env_first = blockIdx.x * p.E + wave_first_g;
-    if (env_first >= p.B) return;          /* whole wave past the batch end */
+    if (!FUSED && env_first >= p.B) return;          /* whole wave past the batch end */
     const bool env_ok = env < p.B;
     const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
     Quad<POS64, SH> q;
-    quad_load<POS64, SH>(p, base, quad_ok, q);
-    const float4* shp = p.s.share + (size_t)(env_ok ? env : env_first) * 3;
+    float4* lds_share = (float4*)lds_raw;            /* FUSED: [E][3] float4, then the obs staging */
+    if constexpr (FUSED) {
+        /* threads that run the ownship phase fetch their quad AFTER it, so the fp64 phase and the
+         * quad never share the register file (keeps the kernel at 64 VGPRs = 8 waves/SIMD); every
+         * other thread has its loads in flight while it waits at the barrier */
+        const bool does_own = tid < p.E;
+        if (!does_own) quad_load<POS64, SH>(p, base, quad_ok, q);
+        if (does_own) {
+            const int e = blockIdx.x * p.E + tid;
+            if (e < p.B) own_compute<RNG>(p, cv, e, lds_share + 3 * tid);
+            quad_load<POS64, SH>(p, base, quad_ok, q);
+        }
+        __syncthreads();
+        if (env_first >= p.B) return;
+    } else {
+        quad_load<POS64, SH>(p, base, quad_ok, q);
+    }
+    const float4* shp = FUSED ? (const float4*)(lds_share + 3 * (env_ok ? g : wave_first_g))
+                              : (const float4*)(p.s.share + (size_t)(env_ok ? env : env_first) * 3);
     const float4 s0 = shp[0];              /* same address for the whole lane group: one broadcast load */
     const float ox = s0.x, oy = s0.y;
 
@@ -933,7 +960,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (p.obs && !(UAM_ABLATE & 2)) {
-        float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
+        float* stage = (float*)(lds_raw + (FUSED ? (size_t)p.E * 48 : 0)) + (size_t)wave_first_g * p.D;
         obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
     }
 }

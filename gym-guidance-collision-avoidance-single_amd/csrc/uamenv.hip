@@ -45,6 +45,7 @@ struct uam_env {
     std::vector<hipEvent_t> kev;  /* 3 events per sampled step (before own, between, after sweep) */
     bool ktiming;
     int ksamples;
+    bool fused;                 /* lean configuration: ownship phase fused into the sweep launch */
     UamCold* cold;              /* device copy of the cold configuration */
     UamCold hcold;              /* host copy, passed by value to the ownship kernel */
     UamDev s;
@@ -254,6 +255,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->E = T / L;
     e->D = uam_obs_dim(cfg);
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
+    e->fused = cfg->precision == UAM_POS_F32 && cfg->rng_mode == UAM_RNG_PHILOX && !e->hold_sh && !cfg->random_own_start;
+    if (const char* fz = getenv("UAMENV_FUSED")) e->fused = e->fused && atoi(fz) != 0;   /* development override */
 
     const size_t BI = (size_t)B * e->Np;
     memset(&e->s, 0, sizeof(e->s));
@@ -371,8 +374,17 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
 {
     dim3 grid(grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
-    if (e->cfg.random_own_start) hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false>), grid, block, lds, st, p);
+    if constexpr (UAM_LEAN(POS64, RNG, SH)) {
+        if (e->fused) {   /* ownship phase inside the sweep launch */
+            hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p,
+                               e->hcold);
+            return;
+        }
+    }
+    if (e->cfg.random_own_start)
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, false>), grid, block, lds, st, p, e->hcold);
+    else
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, false>), grid, block, lds, st, p, e->hcold);
 }
 
 template <bool POS64, int RNG>
@@ -393,8 +405,10 @@ static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
     hipEvent_t* ev = sample ? &e->kev[(size_t)3 * e->ksamples] : nullptr;
     dim3 ogrid((e->cfg.num_envs + 63) / 64), oblock(64);
     if (sample) (void)hipEventRecord(ev[0], st);
-    if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p, e->hcold);
-    else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p, e->hcold);
+    if (!e->fused) {
+        if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p, e->hcold);
+        else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p, e->hcold);
+    }
     if (sample) (void)hipEventRecord(ev[1], st);
     if (x && mt) launch_sweep_t<true, UAM_RNG_MT19937>(e, p, st);
     else if (x) launch_sweep_t<true, UAM_RNG_PHILOX>(e, p, st);
