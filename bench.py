@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--intruders", type=int, default=N_INTRUDERS)
     ap.add_argument("--policy", default="random", choices=["random", "goal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="discrete9", help="exploration only: env variant (default = the BASELINE workload)")
+    ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
     args = ap.parse_args()
 
     import torch
@@ -92,19 +95,24 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     B, N = args.batch, args.intruders
-    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="discrete9", rng="philox", precision="f32", seed=0,
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=args.variant, rng=args.rng, precision=args.precision, seed=0,
                                           auto_reset=True, device=local_rank, env_id_offset=rank * B)
     dev = env.device
     env.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
-    tape = torch.randint(0, 9, (TAPE_LEN, B), dtype=torch.int32, device=dev, generator=gen)
+    if env.cfg.action_mode == 0:
+        tape = torch.randint(0, 9, (TAPE_LEN, B), dtype=torch.int32, device=dev, generator=gen)
+    elif env.cfg.action_mode == 1:
+        tape = torch.randint(0, 3, (TAPE_LEN, B, 2), dtype=torch.int32, device=dev, generator=gen)
+    else:
+        tape = torch.rand((TAPE_LEN, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
     rew_slab = torch.empty((GATHER_EVERY, B), dtype=torch.float32, device=dev)
     done_slab = torch.empty((GATHER_EVERY, B), dtype=torch.uint8, device=dev)
     if world > 1:
         rew_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.float32, device=dev)
         done_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.uint8, device=dev)
-    acts = torch.empty((B,), dtype=torch.int32, device=dev)
+    acts = env.policy_actions("random")
 
     def run(nsteps, offset=0):
         for k in range(nsteps):
@@ -152,9 +160,13 @@ def main():
         total_env_steps = float(B) * world * args.steps
         value = total_env_steps / elapsed
         step_bytes = env.step_bytes                      # (40 N + 150) B per env-step, SURVEY §8d
-        own_bytes = 88 * B                               # ownship/goal/action/counter share of the 150 B
-        sweep_bytes = step_bytes - own_bytes             # (40 N + 62) B per env: what uam_sweep_kernel must move
-        achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+        fused = own_ms == 0.0                            # float32/Philox: ownship phase runs inside the sweep launch
+        own_bytes = 0 if fused else 88 * B               # ownship/goal/action/counter share of the 150 B
+        sweep_bytes = step_bytes - own_bytes             # what the dominant kernel must move per launch
+        # fused: the step IS the sweep launch, so the hipEvents that bracket the timed region (divided by the
+        # launches) give its average duration without the perturbation of per-launch event records
+        dom_ms = kernel_ms if fused else sweep_ms
+        achieved = sweep_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc_path) and B == B_PER_GPU and N == N_INTRUDERS:
@@ -165,16 +177,18 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU "
-                                   "(BASELINE.json configs[2], roofline run)" % (B, N),
-                       "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": "philox",
-                       "positions": "float32", "obs": "float32[B,%d] written every step" % env.obs_dim,
+            "config": {"workload": ("SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU "
+                                    "(BASELINE.json configs[2], roofline run)" % (B, N)) if args.variant == "discrete9"
+                       else "%s variant, batch=%d x %d intruders per GPU" % (args.variant, B, N),
+                       "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": args.rng,
+                       "variant": args.variant, "positions": "float32" if args.precision == "f32" else "float64 (exact promotion)", "obs": "float32[B,%d] written every step" % env.obs_dim,
                        "exchange": "none" if world == 1 else "all_gather(reward,done) every %d steps" % GATHER_EVERY},
             "pair_steps_per_sec": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "uam_sweep_kernel<f32,philox,straight>", "bytes_per_launch": sweep_bytes,
-                         "avg_launch_ms": sweep_ms, "sampled_launches": nsamp,
+                         "kernel": "uam_sweep_kernel (ownship phase fused)" if fused else "uam_sweep_kernel",
+                         "bytes_per_launch": sweep_bytes,
+                         "avg_launch_ms": dom_ms, "bracketed_launch_ms": sweep_ms, "sampled_launches": nsamp,
                          "own_kernel_avg_ms": own_ms,
                          "whole_step": {"bytes": step_bytes, "avg_ms": kernel_ms,
                                         "frac": step_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},

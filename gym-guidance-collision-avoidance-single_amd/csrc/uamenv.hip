@@ -607,7 +607,7 @@ extern "C" int uam_kernel_timing_read(uam_env* e, void* stream, float* own_ms_ou
         own += a; sweep += b;
     }
     *samples_out = e->ksamples;
-    *own_ms_out = e->ksamples ? (float)(own / e->ksamples) : 0.f;
+    *own_ms_out = (e->ksamples && !e->fused) ? (float)(own / e->ksamples) : 0.f;   /* fused: no separate ownship launch */
     *sweep_ms_out = e->ksamples ? (float)(sweep / e->ksamples) : 0.f;
     e->ksamples = 0;
     return UAM_OK;

@@ -168,7 +168,8 @@ int uam_seed(uam_env* env, const uint64_t* seeds_host);
  * obs_out: float32[B, D] device or NULL; rows of un-masked envs receive their current observation. */
 int uam_reset(uam_env* env, const uint8_t* mask_dev, float* obs_out, void* stream);
 
-/* One env.step() for every env of the batch, fused into one kernel launch.
+/* One env.step() for every env of the batch: one launch in the float32/Philox configuration (ownship
+ * phase fused into the intruder sweep), two dependent launches otherwise.
  *   actions   : device, per uam_config.action_mode
  *   obs_out   : float32[B, D] device or NULL
  *   reward_out: float32[B]   device
@@ -211,7 +212,8 @@ int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
 /* Per-kernel device times.  While enabled, every uam_step brackets its two launches with hipEvents
  * (up to 256 steps are sampled; this serialises the launches slightly, so keep it out of throughput
  * runs).  uam_kernel_timing_read synchronises `stream` and returns the mean duration in milliseconds of
- * the ownship kernel and of the intruder-sweep kernel over the sampled steps. */
+ * the ownship kernel and of the intruder-sweep kernel over the sampled steps (the ownship figure is 0
+ * in the float32/Philox configuration, where that phase runs inside the sweep launch). */
 int uam_kernel_timing(uam_env* env, int32_t enable);
 int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out);
 
