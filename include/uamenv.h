@@ -217,6 +217,58 @@ int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
 int uam_kernel_timing(uam_env* env, int32_t enable);
 int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out);
 
+/* ======================================================================================================
+ * Batched MCTS forward model + UCT search (the caller that dominates config 5's
+ * wall-clock).  Replaces, for B root states at once:
+ *   SingleAircraftState.move / reward / is_terminal_state   Algorithms/MCTS/nodes_single_randintru.py:25-114
+ *   SingleAircraftNode.expand / rollout / backpropagate     Algorithms/MCTS/nodes_single_randintru.py:202-224
+ *   MCTSNode.best_child / rollout_policy                    Algorithms/MCTS/common.py:47-55
+ *   MCTS.best_action / tree_policy                          Algorithms/MCTS/search_single.py:8-22
+ * A root state is the RandIntruder observation vector [x,y,vx,vy,speed,heading]*N + own[x,y,vx,vy,speed,
+ * heading] + goal[x,y] (6N+8 float64).  Randomness is Philox (key = seed; counter = (root id,
+ * sim<<4 | move, frame<<8 | purpose, intruder)), so results are independent of batching.
+ * ====================================================================================================== */
+typedef struct uam_mcts_config {
+    uint32_t struct_size;
+    int32_t  num_intruders;      /* N, 1..256 */
+    int32_t  simulations;        /* Config.no_simulation = 100   config_single.py:60 */
+    int32_t  search_depth;       /* Config.search_depth  = 3     config_single.py:61 */
+    int32_t  simulate_frame;     /* Config.simulate_frame = 10   config_single.py:59 */
+    int32_t  reserved0;
+    uint64_t seed;
+    double window_width, window_height, minimum_separation;                 /* config_single.py:6-7,16 */
+    double min_speed, max_speed, d_speed, speed_sigma, position_sigma;      /* :23-27 */
+    double d_heading, heading_sigma;                                        /* :30-31 */
+    double heading_change_prob, heading_change_max_deg;                     /* nodes_single_randintru.py:64-65 */
+    double c_param;              /* best_child default 1.4, common.py:47 */
+    double reward_div;           /* 1200.0, nodes_single_randintru.py:31 */
+} uam_mcts_config;
+
+int uam_mcts_config_default(uam_mcts_config* cfg, int32_t num_intruders);
+
+/* Root states of every env of a RAW6 (RandIntruder) handle, straight from its SoA state (float64, no
+ * float32 observation rounding): roots_out = double[B, 6N+8] device. */
+int uam_mcts_roots_from_env(uam_env* env, double* roots_out, void* stream);
+
+/* MCTS(root).best_action(simulations, search_depth) for B roots at once, one wavefront per root.
+ *   roots        : double[B, 6N+8] device
+ *   root_id0     : global index of root 0 (Philox counter word 0 = root_id0 + b)
+ *   workspace    : device scratch of at least uam_mcts_workspace_bytes(cfg, B) bytes
+ *   actions_out  : int32[B, 2] device, best_node.state.prev_action
+ *   child_q_out / child_n_out : double[B, 9] device or NULL, root children's q and n in expansion order
+ *                  (child k holds action (2,2)-k: untried_actions.pop() takes the list's tail) */
+int64_t uam_mcts_workspace_bytes(const uam_mcts_config* cfg, int32_t num_roots);
+int uam_mcts_best_action(const uam_mcts_config* cfg, int device_id, const double* roots, int32_t num_roots,
+                         uint32_t root_id0, void* workspace, int32_t* actions_out, double* child_q_out,
+                         double* child_n_out, void* stream);
+
+/* One SingleAircraftState.move(action) per root (no tree): next_out double[B, 6N+8], flags_out uint8[B,3]
+ * (hit_wall, conflict, reach_goal), reward_out double[B] (state.reward()).  Philox counter uses
+ * sim = sim_index, move = move_index. */
+int uam_mcts_move(const uam_mcts_config* cfg, int device_id, const double* states, const int32_t* actions,
+                  int32_t num_states, uint32_t root_id0, uint32_t sim_index, uint32_t move_index,
+                  double* next_out, uint8_t* flags_out, double* reward_out, void* stream);
+
 const char* uam_last_error(void);
 const char* uam_version(void);
 

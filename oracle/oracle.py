@@ -58,6 +58,21 @@ class UamStateView(C.Structure):
     ]
 
 
+class UamMctsConfig(C.Structure):
+    """Mirror of `uam_mcts_config` (include/uamenv.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("num_intruders", C.c_int32), ("simulations", C.c_int32),
+        ("search_depth", C.c_int32), ("simulate_frame", C.c_int32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint64),
+        ("window_width", C.c_double), ("window_height", C.c_double), ("minimum_separation", C.c_double),
+        ("min_speed", C.c_double), ("max_speed", C.c_double), ("d_speed", C.c_double),
+        ("speed_sigma", C.c_double), ("position_sigma", C.c_double),
+        ("d_heading", C.c_double), ("heading_sigma", C.c_double),
+        ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
+        ("c_param", C.c_double), ("reward_div", C.c_double),
+    ]
+
+
 STATE_FIELDS = {
     # name: (dtype, per-intruder?)
     "int_x": (np.float64, True), "int_y": (np.float64, True),
@@ -140,6 +155,13 @@ def lib():
         L.orc_pmath_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_pmath_log.argtypes = [C.c_double]
         L.orc_pmath_log.restype = C.c_double
+        L.uam_mcts_config_default.argtypes = [C.POINTER(UamMctsConfig), C.c_int32]
+        L.orc_mcts_move.argtypes = [C.POINTER(UamMctsConfig), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_mcts_best_action.argtypes = [C.POINTER(UamMctsConfig), C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -267,3 +289,37 @@ def pmath_sincos(x):
 
 def pmath_log(x):
     return lib().orc_pmath_log(float(x))
+
+
+def mcts_config(N, **over):
+    cfg = UamMctsConfig()
+    lib().uam_mcts_config_default(C.byref(cfg), N)
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def mcts_move(cfg, state, action, rng_mode=RNG_MT19937, math_impl=MATH_LIBM, np_seed=0, root_id=0, sim=0, move=0):
+    """SingleAircraftState(state).move(action) -> (next_state, flags[3], reward, mt_pos)."""
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    nxt = np.zeros_like(st)
+    flags = np.zeros(3, dtype=np.uint8)
+    rew, pos = C.c_double(0), C.c_int(0)
+    lib().orc_mcts_move(C.byref(cfg), rng_mode, math_impl, np_seed, root_id, sim, move, st.ctypes.data,
+                        int(action[0]), int(action[1]), nxt.ctypes.data, flags.ctypes.data, C.byref(rew), C.byref(pos))
+    return nxt, flags, rew.value, pos.value
+
+
+def mcts_best_action(cfg, root_state, rng_mode=RNG_MT19937, math_impl=MATH_LIBM, np_seed=0, root_id=0):
+    """MCTS(root).best_action(cfg.simulations, cfg.search_depth) -> dict."""
+    st = np.ascontiguousarray(root_state, dtype=np.float64)
+    best = np.zeros(2, dtype=np.int32)
+    ca = np.zeros((9, 2), dtype=np.int32)
+    cq, cn = np.zeros(9), np.zeros(9)
+    rn, nn, pos = C.c_double(0), C.c_int(0), C.c_int(0)
+    lib().orc_mcts_best_action(C.byref(cfg), rng_mode, math_impl, np_seed, root_id, st.ctypes.data, best.ctypes.data,
+                               ca.ctypes.data, cq.ctypes.data, cn.ctypes.data, C.byref(rn), C.byref(nn), C.byref(pos))
+    return dict(best_action=best, child_action=ca, child_q=cq, child_n=cn, root_n=rn.value, n_nodes=nn.value,
+                rng_pos=pos.value)

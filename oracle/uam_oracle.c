@@ -753,3 +753,275 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
     return 0;
 }
 #endif
+
+/* ====================================================================== MCTS forward model + UCT search
+ * Restates Algorithms/MCTS/nodes_single_randintru.py (SingleAircraftState / SingleAircraftNode),
+ * common.py (MCTSNode.best_child, rollout_policy) and search_single.py (MCTS.best_action, tree_policy).
+ * Third-party arithmetic: NumPy scalar `x**2` is libm pow(x, 2.0) (differs from x*x by 1 ulp in ~0.09 %
+ * of cases, probed); legacy RandomState.randint(9) = masked rejection on one 32-bit word per attempt. */
+enum { MPH_HEADCHG = 1, MPH_OWN = 2, MPH_POS = 3, MPH_ACTION = 4 };
+
+typedef struct {
+    const uam_mcts_config* c;
+    int rng_mode, math_impl;
+    mt_state mt;
+    uint32_t root_id, sim, mv;
+    orc_batch fake;   /* carries math_impl for mt_gauss/m_log */
+} mcts_ctx;
+
+#ifndef UAM_ORACLE_NO_CONFIG
+/* Algorithms/MCTS/config_single.py:4-64 */
+int uam_mcts_config_default(uam_mcts_config* c, int32_t N)
+{
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->num_intruders = N;
+    c->simulations = 100; c->search_depth = 3; c->simulate_frame = 10;
+    const double scale = 30.0;
+    c->window_width = 800; c->window_height = 800; c->minimum_separation = 555 / scale;
+    c->min_speed = 50 / scale; c->max_speed = 80 / scale; c->d_speed = 5 / scale;
+    c->speed_sigma = 0 / scale; c->position_sigma = 0 / scale;
+    c->d_heading = 5 * (M_PI / 180.0); c->heading_sigma = 2 * (M_PI / 180.0);
+    c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
+    c->c_param = 1.4; c->reward_div = 1200.0;
+    return 0;
+}
+#endif
+
+static void mphilox(const mcts_ctx* m, uint32_t frame, uint32_t purpose, uint32_t idx, uint32_t out[4])
+{
+    uint32_t ctr[4] = { m->root_id, (m->sim << 4) | m->mv, (frame << 8) | purpose, idx };
+    uint32_t key[2] = { (uint32_t)m->c->seed, (uint32_t)(m->c->seed >> 32) };
+    orc_philox4x32_10(ctr, key, out);
+}
+
+static void mphilox_normals(const mcts_ctx* m, uint32_t frame, uint32_t purpose, uint32_t idx, double* z0, double* z1)
+{
+    uint32_t w[4];
+    mphilox(m, frame, purpose, idx, w);
+    double u1 = u53_open0(w[0], w[1]), u2 = u53(w[2], w[3]);
+    double r = sqrt(-2.0 * m_log(&m->fake, u1));
+    double sn, cs;
+    m_sincos(&m->fake, 2.0 * M_PI * u2, &sn, &cs);
+    *z0 = r * cs;
+    *z1 = r * sn;
+}
+
+/* metric(): np.sqrt(dx**2 + dy**2), nodes_single_randintru.py:137-140 */
+static double mcts_metric(const mcts_ctx* m, double x1, double y1, double x2, double y2)
+{
+    double dx = x1 - x2, dy = y1 - y2;
+    if (m->math_impl == ORC_MATH_LIBM) return sqrt(pow(dx, 2.0) + pow(dy, 2.0));
+    return sqrt(dx * dx + dy * dy);
+}
+
+/* SingleAircraftState.move, nodes_single_randintru.py:39-114 */
+static void mcts_move(mcts_ctx* m, const double* s_in, int a0, int a1, double* s, int* hit_wall, int* conflict,
+                      int* reach_goal)
+{
+    const uam_mcts_config* c = m->c;
+    const int N = c->num_intruders, len = 6 * N + 8;
+    memcpy(s, s_in, sizeof(double) * (size_t)len);
+    double* own = s + 6 * N;     /* x, y, vx, vy, speed, heading, goalx, goaly */
+    *hit_wall = *conflict = *reach_goal = 0;
+    const double d_heading = (a0 - 1) * c->d_heading;
+    const double accel = (a1 - 1) * c->d_speed;
+    for (int f = 0; f < c->simulate_frame; f++) {
+        for (int i = 0; i < N; i++) {
+            double* it = s + 6 * i;
+            double vx = it[2], vy = it[3], speed = it[4], heading = it[5];
+            double nx_, ny_, p, ud = 0.0;
+            if (m->rng_mode == UAM_RNG_MT19937) {
+                nx_ = 0.0 + c->position_sigma * mt_gauss(&m->fake, &m->mt);
+                ny_ = 0.0 + c->position_sigma * mt_gauss(&m->fake, &m->mt);
+                it[0] += vx + nx_;
+                it[1] += vy + ny_;
+                p = mt_double(&m->mt);                                        /* np.random.random() */
+                if (p < c->heading_change_prob) ud = mt_double(&m->mt);
+            } else {
+                if (c->position_sigma != 0.0) {
+                    double z0, z1;
+                    mphilox_normals(m, (uint32_t)f, MPH_POS, (uint32_t)i, &z0, &z1);
+                    nx_ = 0.0 + c->position_sigma * z0; ny_ = 0.0 + c->position_sigma * z1;
+                } else { nx_ = 0.0; ny_ = 0.0; }
+                it[0] += vx + nx_;
+                it[1] += vy + ny_;
+                uint32_t w[4];
+                mphilox(m, (uint32_t)f, MPH_HEADCHG, (uint32_t)i, w);
+                p = u32d(w[0]);
+                ud = u32d(w[1]);
+            }
+            if (p < c->heading_change_prob) {                                 /* :64-70 */
+                double deg = -c->heading_change_max_deg + (c->heading_change_max_deg - (-c->heading_change_max_deg)) * ud;
+                heading += deg * (M_PI / 180.0);
+                double sn, cs;
+                m_sincos(&m->fake, heading, &sn, &cs);
+                it[2] = speed * cs; it[3] = speed * sn; it[5] = heading;
+            }
+        }
+        double zs, zh;
+        if (m->rng_mode == UAM_RNG_MT19937) {
+            own[4] += accel;                                                  /* :73-79 (speed first, then heading) */
+            own[4] = fmax(c->min_speed, fmin(own[4], c->max_speed));
+            zs = mt_gauss(&m->fake, &m->mt);
+            own[4] += 0.0 + c->speed_sigma * zs;
+            own[5] += d_heading;
+            zh = mt_gauss(&m->fake, &m->mt);
+            own[5] += 0.0 + c->heading_sigma * zh;
+        } else {
+            mphilox_normals(m, (uint32_t)f, MPH_OWN, 0, &zs, &zh);
+            own[4] += accel;
+            own[4] = fmax(c->min_speed, fmin(own[4], c->max_speed));
+            own[4] += 0.0 + c->speed_sigma * zs;
+            own[5] += d_heading;
+            own[5] += 0.0 + c->heading_sigma * zh;
+        }
+        double sn, cs;
+        m_sincos(&m->fake, own[5], &sn, &cs);
+        const double ovx = own[4] * cs, ovy = own[4] * sn;
+        own[0] += ovx; own[1] += ovy; own[2] = ovx; own[3] = ovy;
+        const double ox = own[0], oy = own[1];
+        if (!(0 < ox && ox < c->window_width) || !(0 < oy && oy < c->window_height)) { *hit_wall = 1; break; }   /* :94-96 */
+        for (int i = 0; i < N; i++)
+            if (mcts_metric(m, s[6 * i], s[6 * i + 1], ox, oy) < c->minimum_separation) { *conflict = 1; break; }
+        if (*conflict) break;
+        if (mcts_metric(m, ox, oy, own[6], own[7]) < c->minimum_separation) { *reach_goal = 1; break; }          /* :109 */
+    }
+}
+
+/* SingleAircraftState.reward, :25-32 */
+static double mcts_reward(const mcts_ctx* m, const double* s, int hit_wall, int conflict, int reach_goal)
+{
+    if (hit_wall || conflict) return 0.0;
+    if (reach_goal) return 1.0;
+    const double* own = s + 6 * m->c->num_intruders;
+    double dx = own[0] - own[6], dy = own[1] - own[7];
+    double d = m->math_impl == ORC_MATH_LIBM ? sqrt(pow(dx, 2.0) + pow(dy, 2.0)) : sqrt(dx * dx + dy * dy);
+    return 1 - d / m->c->reward_div;
+}
+
+static void mcts_ctx_init(mcts_ctx* m, const uam_mcts_config* cfg, int rng_mode, int math_impl, uint32_t np_seed,
+                          uint32_t root_id)
+{
+    memset(m, 0, sizeof(*m));
+    m->c = cfg; m->rng_mode = rng_mode; m->math_impl = math_impl; m->root_id = root_id;
+    m->fake.math_impl = math_impl;
+    if (rng_mode == UAM_RNG_MT19937) mt_seed(&m->mt, np_seed);
+}
+
+void orc_mcts_move(const uam_mcts_config* cfg, int rng_mode, int math_impl, uint32_t np_seed, uint32_t root_id,
+                   uint32_t sim_index, uint32_t move_index, const double* state, int a0, int a1, double* next_out,
+                   uint8_t* flags3_out, double* reward_out, int* rng_pos_out)
+{
+    mcts_ctx m;
+    mcts_ctx_init(&m, cfg, rng_mode, math_impl, np_seed, root_id);
+    m.sim = sim_index; m.mv = move_index;
+    int hw, cf, rg;
+    mcts_move(&m, state, a0, a1, next_out, &hw, &cf, &rg);
+    flags3_out[0] = (uint8_t)hw; flags3_out[1] = (uint8_t)cf; flags3_out[2] = (uint8_t)rg;
+    *reward_out = mcts_reward(&m, next_out, hw, cf, rg);
+    if (rng_pos_out) *rng_pos_out = m.mt.pos;
+}
+
+typedef struct {
+    int parent, depth, nchild, hit_wall, conflict, reach_goal, a0, a1;
+    int child[9];
+    double q, n;
+    double* state;
+} mnode;
+
+static int mnode_terminal(const mnode* nd, int search_depth)
+{
+    return nd->reach_goal || nd->conflict || nd->hit_wall || nd->depth == search_depth;   /* :34-37 */
+}
+
+/* np.random.randint(9): masked rejection, one 32-bit word per attempt */
+static int mcts_rollout_action(mcts_ctx* m)
+{
+    if (m->rng_mode == UAM_RNG_MT19937) {
+        uint32_t v;
+        do { v = mt_u32(&m->mt) & 0xFu; } while (v > 8u);
+        return (int)v;
+    }
+    uint32_t w[4];
+    mphilox(m, 0, MPH_ACTION, 0, w);
+    return (int)(((uint64_t)w[0] * 9u) >> 32);
+}
+
+void orc_mcts_best_action(const uam_mcts_config* cfg, int rng_mode, int math_impl, uint32_t np_seed, uint32_t root_id,
+                          const double* root_state, int32_t* best_action2, int32_t* child_action18,
+                          double* child_q9, double* child_n9, double* root_n_out, int* n_nodes_out, int* rng_pos_out)
+{
+    const int len = 6 * cfg->num_intruders + 8;
+    const int cap = cfg->simulations + 1;
+    mcts_ctx m;
+    mcts_ctx_init(&m, cfg, rng_mode, math_impl, np_seed, root_id);
+    mnode* nodes = (mnode*)calloc((size_t)cap, sizeof(mnode));
+    double* pool = (double*)malloc(sizeof(double) * (size_t)len * (size_t)cap);
+    double* cur = (double*)malloc(sizeof(double) * (size_t)len);
+    double* nxt = (double*)malloc(sizeof(double) * (size_t)len);
+    for (int i = 0; i < cap; i++) nodes[i].state = pool + (size_t)i * len;
+    memcpy(nodes[0].state, root_state, sizeof(double) * (size_t)len);
+    nodes[0].parent = -1;
+    int nn = 1;
+    for (int sim = 0; sim < cfg->simulations; sim++) {
+        m.sim = (uint32_t)sim; m.mv = 0;
+        /* tree_policy, search_single.py:15-22 */
+        int v = 0;
+        while (!mnode_terminal(&nodes[v], cfg->search_depth)) {
+            if (nodes[v].nchild < 9) {
+                /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
+                const int k = 8 - nodes[v].nchild;
+                mnode* ch = &nodes[nn];
+                ch->parent = v; ch->depth = nodes[v].depth + 1; ch->a0 = k / 3; ch->a1 = k % 3;
+                mcts_move(&m, nodes[v].state, ch->a0, ch->a1, ch->state, &ch->hit_wall, &ch->conflict, &ch->reach_goal);
+                m.mv++;
+                nodes[v].child[nodes[v].nchild++] = nn;
+                v = nn++;
+                break;
+            }
+            /* best_child(c_param), common.py:47-52 */
+            int best = 0;
+            double bw = 0;
+            for (int j = 0; j < nodes[v].nchild; j++) {
+                const mnode* c = &nodes[nodes[v].child[j]];
+                double w = (c->q / c->n) + cfg->c_param * sqrt((2 * m_log(&m.fake, nodes[v].n) / c->n));
+                if (j == 0 || w > bw) { bw = w; best = j; }
+            }
+            v = nodes[v].child[best];
+        }
+        /* rollout, nodes_single_randintru.py:212-218 */
+        memcpy(cur, nodes[v].state, sizeof(double) * (size_t)len);
+        int hw = nodes[v].hit_wall, cf = nodes[v].conflict, rg = nodes[v].reach_goal, depth = nodes[v].depth;
+        while (!(rg || cf || hw || depth == cfg->search_depth)) {
+            const int a = mcts_rollout_action(&m);
+            mcts_move(&m, cur, a / 3, a % 3, nxt, &hw, &cf, &rg);
+            m.mv++;
+            double* t = cur; cur = nxt; nxt = t;
+            depth++;
+        }
+        const double r = mcts_reward(&m, cur, hw, cf, rg);
+        for (int u = v; u >= 0; u = nodes[u].parent) { nodes[u].n += 1.; nodes[u].q += r; }   /* backpropagate */
+    }
+    /* best_child(c_param=0.) of the root */
+    int best = 0;
+    double bw = 0;
+    for (int j = 0; j < nodes[0].nchild; j++) {
+        const mnode* c = &nodes[nodes[0].child[j]];
+        double w = (c->q / c->n) + 0. * sqrt((2 * m_log(&m.fake, nodes[0].n) / c->n));
+        if (j == 0 || w > bw) { bw = w; best = j; }
+    }
+    best_action2[0] = nodes[nodes[0].child[best]].a0;
+    best_action2[1] = nodes[nodes[0].child[best]].a1;
+    for (int j = 0; j < 9; j++) {
+        const int has = j < nodes[0].nchild;
+        const mnode* c = has ? &nodes[nodes[0].child[j]] : NULL;
+        if (child_action18) { child_action18[2 * j] = has ? c->a0 : -1; child_action18[2 * j + 1] = has ? c->a1 : -1; }
+        if (child_q9) child_q9[j] = has ? c->q : 0.0;
+        if (child_n9) child_n9[j] = has ? c->n : 0.0;
+    }
+    if (root_n_out) *root_n_out = nodes[0].n;
+    if (n_nodes_out) *n_nodes_out = nn;
+    if (rng_pos_out) *rng_pos_out = m.mt.pos;
+    free(nodes); free(pool); free(cur); free(nxt);
+}

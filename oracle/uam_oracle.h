@@ -55,6 +55,16 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_pmath_sincos(double x, double* s, double* c);
 double orc_pmath_log(double x);
 
+/* ---- MCTS forward model + UCT search (Algorithms/MCTS/nodes_single_randintru.py, common.py,
+ * search_single.py).  rng_mode UAM_RNG_MT19937: the process-global NumPy stream freshly seeded with
+ * np_seed (what the golden fixtures did); UAM_RNG_PHILOX: the product's counter scheme. */
+void orc_mcts_move(const uam_mcts_config* cfg, int rng_mode, int math_impl, uint32_t np_seed, uint32_t root_id,
+                   uint32_t sim_index, uint32_t move_index, const double* state, int a0, int a1, double* next_out,
+                   uint8_t* flags3_out, double* reward_out, int* rng_pos_out);
+void orc_mcts_best_action(const uam_mcts_config* cfg, int rng_mode, int math_impl, uint32_t np_seed, uint32_t root_id,
+                          const double* root_state, int32_t* best_action2, int32_t* child_action18,
+                          double* child_q9, double* child_n9, double* root_n_out, int* n_nodes_out, int* rng_pos_out);
+
 #ifdef __cplusplus
 }
 #endif
