@@ -11,9 +11,10 @@ from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2E
                    SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv, make_config)
 from . import spaces
 from .sharded import ShardedSingleAircraftEnv, shard_bounds
+from .mcts import BatchedMCTS, mcts_config
 
 __all__ = [
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
     "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv", "make_config",
-    "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds",
+    "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds", "BatchedMCTS", "mcts_config",
 ]

@@ -64,6 +64,21 @@ class UamStateView(C.Structure):
     ]
 
 
+class UamMctsConfig(C.Structure):
+    """`uam_mcts_config` (include/uamenv.h): Algorithms/MCTS/config_single.py snapshot + search parameters."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("num_intruders", C.c_int32), ("simulations", C.c_int32),
+        ("search_depth", C.c_int32), ("simulate_frame", C.c_int32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint64),
+        ("window_width", C.c_double), ("window_height", C.c_double), ("minimum_separation", C.c_double),
+        ("min_speed", C.c_double), ("max_speed", C.c_double), ("d_speed", C.c_double),
+        ("speed_sigma", C.c_double), ("position_sigma", C.c_double),
+        ("d_heading", C.c_double), ("heading_sigma", C.c_double),
+        ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
+        ("c_param", C.c_double), ("reward_div", C.c_double),
+    ]
+
+
 STATE_FIELDS = {
     "int_x": (np.float64, "BN"), "int_y": (np.float64, "BN"),
     "int_vx": (np.float32, "BN"), "int_vy": (np.float32, "BN"),
@@ -99,6 +114,12 @@ SYMBOLS = [
     ("uam_timing_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     ("uam_kernel_timing", C.c_int, [_P, C.c_int32]),
     ("uam_kernel_timing_read", C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    ("uam_mcts_config_default", C.c_int, [C.POINTER(UamMctsConfig), C.c_int32]),
+    ("uam_mcts_roots_from_env", C.c_int, [_P, _P, _P]),
+    ("uam_mcts_workspace_bytes", C.c_int64, [C.POINTER(UamMctsConfig), C.c_int32]),
+    ("uam_mcts_best_action", C.c_int, [C.POINTER(UamMctsConfig), C.c_int, _P, C.c_int32, C.c_uint32, _P, _P, _P, _P, _P]),
+    ("uam_mcts_move", C.c_int, [C.POINTER(UamMctsConfig), C.c_int, _P, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                _P, _P, _P, _P]),
     ("uam_last_error", C.c_char_p, []),
     ("uam_version", C.c_char_p, []),
 ]

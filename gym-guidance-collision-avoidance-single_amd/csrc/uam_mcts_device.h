@@ -1,0 +1,407 @@
+/*
+ * uam_mcts_device.h — batched MCTS forward model + UCT search on gfx950.
+ *
+ * Restates, for B root states at once (reference paths relative to the upstream root):
+ *   SingleAircraftState.move / reward / is_terminal_state   Algorithms/MCTS/nodes_single_randintru.py:25-114
+ *   SingleAircraftNode.expand / rollout / backpropagate     Algorithms/MCTS/nodes_single_randintru.py:202-224
+ *   MCTSNode.best_child / rollout_policy                    Algorithms/MCTS/common.py:47-55
+ *   MCTS.best_action / tree_policy                          Algorithms/MCTS/search_single.py:8-22
+ *
+ * Execution shape: ONE WAVEFRONT PER ROOT.  UCT is sequential in its simulations, so the parallelism is
+ * (a) across roots and (b) across the intruders inside every simulated frame of move(): lane l holds
+ * intruders l, l+64, ... in registers (float64, like the reference's state vector).  Tree bookkeeping
+ * (n, q, parent, children, flags, stored rewards) lives in LDS, one slab per wave; the per-node states
+ * that may still be expanded live in HBM ([node][field][intruder], coalesced over lanes) — a root's
+ * whole tree is ~270 KB at N=64, 2.2 GB for 8192 roots, which is what 288 GB of HBM is for.
+ * Wave-uniform quantities (ownship state, UCT weights) are computed redundantly by every lane: the
+ * instruction stream is issued once per wave either way.
+ *
+ * Randomness: Philox4x32-10, key = seed, counter = (root id, sim<<4 | move, (frame>>1)<<8 | purpose,
+ * intruder).  Heading-change draws and the ownship normals are produced per FRAME PAIR (one block / one
+ * Box-Muller pair serves two frames).  Zero sigmas (the shipped MCTS config has position_sigma =
+ * speed_sigma = 0) draw nothing: adding N(0,0) is the identity.
+ */
+#ifndef UAM_MCTS_DEVICE_H
+#define UAM_MCTS_DEVICE_H
+
+#include "uam_device.h"
+
+#define UAM_MCTS_MAX_NODES 256          /* simulations + 1 <= 256 (node ids are bytes) */
+#define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
+#define UAM_MCTS_WAVES_PER_BLOCK 2
+
+enum { UAM_MPH_HEADCHG = 1, UAM_MPH_OWN_H = 2, UAM_MPH_POS = 3, UAM_MPH_ACTION = 4, UAM_MPH_OWN_S = 5 };
+
+struct UamMctsParams {
+    int B, N, K, Npad, cap, sims, depth, frames;
+    uint32_t seed_lo, seed_hi, root_id0;
+    uint32_t sim_index, move_index;      /* uam_mcts_move only */
+    double W, H, sep2, min_speed, max_speed, d_speed, speed_sigma, position_sigma, d_heading, heading_sigma,
+        hc_prob, hc_max_deg, c_param, reward_div;
+    const double* roots;                 /* [B][6N+8] */
+    double* pool_int;                    /* [B][cap][5][Npad]: x, y, vx, vy, heading of expandable nodes */
+    double* pool_own;                    /* [B][cap][8] */
+    int32_t* actions_out;                /* [B][2] */
+    double* child_q_out;                 /* [B][9] or NULL */
+    double* child_n_out;
+    const int32_t* actions_in;           /* uam_mcts_move: [B][2] */
+    double* next_out;                    /* uam_mcts_move: [B][6N+8] */
+    uint8_t* flags_out;                  /* [B][3] */
+    double* reward_out;                  /* [B] */
+};
+
+/* tree bookkeeping of one root (one wave) in LDS */
+struct MctsTree {
+    double n[UAM_MCTS_MAX_NODES], q[UAM_MCTS_MAX_NODES], rew[UAM_MCTS_MAX_NODES];
+    uint8_t parent[UAM_MCTS_MAX_NODES], nchild[UAM_MCTS_MAX_NODES], depth[UAM_MCTS_MAX_NODES],
+        term[UAM_MCTS_MAX_NODES], act[UAM_MCTS_MAX_NODES];
+    uint8_t child[UAM_MCTS_MAX_NODES][9];
+};
+
+/* the state vector of one node, distributed over the wave */
+struct MctsState {
+    double x[UAM_MCTS_MAX_SLOTS], y[UAM_MCTS_MAX_SLOTS], vx[UAM_MCTS_MAX_SLOTS], vy[UAM_MCTS_MAX_SLOTS],
+        hd[UAM_MCTS_MAX_SLOTS];
+    double ox, oy, ovx, ovy, osp, ohd;   /* ownship: wave-uniform */
+};
+
+struct MctsRng { uint32_t root, sim, mv, k0, k1; };
+
+__device__ __forceinline__ void mcts_philox(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx, uint32_t* w)
+{
+    uam_philox(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, r.k0, r.k1, w);
+}
+
+__device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx,
+                                             double& z0, double& z1)
+{
+    uint32_t w[4];
+    mcts_philox(r, framepair, purpose, idx, w);
+    const double u1 = uam_u53_open0(w[0], w[1]), u2 = uam_u53(w[2], w[3]);
+    const double rr = __builtin_sqrt(-2.0 * uam_log(u1));
+    double sn, cs;
+    uam_sincos(UAM_TWO_PI * u2, &sn, &cs);
+    z0 = rr * cs;
+    z1 = rr * sn;
+}
+
+/* SingleAircraftState.move, nodes_single_randintru.py:39-114.  `sp` = per-slot intruder speed (constant
+ * over the tree).  Returns flag bits: 1 hit_wall, 2 conflict, 4 reach_goal. */
+template <int K>
+__device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
+                                     const double gx, const double gy, const int a0, const int a1, MctsState& s)
+{
+    const double d_heading = (double)(a0 - 1) * p.d_heading;
+    const double accel = (double)(a1 - 1) * p.d_speed;
+    uint32_t flags = 0;
+    double zh0 = 0.0, zh1 = 0.0, zs0 = 0.0, zs1 = 0.0;
+    uint32_t hw[K][4];
+    for (int f = 0; f < p.frames; f++) {
+        const uint32_t fp = (uint32_t)f >> 1;
+        const int odd = f & 1;
+        /* ---- intruders: position += velocity (+ noise), Bernoulli heading change, :54-70 */
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = lane + 64 * k;
+            if (i < p.N) {
+                double nx_ = 0.0, ny_ = 0.0;
+                if (p.position_sigma != 0.0) {
+                    double z0, z1;
+                    mcts_normals(rng, (uint32_t)f, UAM_MPH_POS, (uint32_t)i, z0, z1);
+                    nx_ = 0.0 + p.position_sigma * z0;
+                    ny_ = 0.0 + p.position_sigma * z1;
+                }
+                s.x[k] += s.vx[k] + nx_;
+                s.y[k] += s.vy[k] + ny_;
+                if (!odd) mcts_philox(rng, fp, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
+                const double pr = uam_u32d(odd ? hw[k][2] : hw[k][0]);
+                if (pr < p.hc_prob) {
+                    const double ud = uam_u32d(odd ? hw[k][3] : hw[k][1]);
+                    const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                    s.hd[k] += deg * UAM_DEG2RAD;
+                    double sn, cs;
+                    uam_sincos(s.hd[k], &sn, &cs);
+                    s.vx[k] = sp[k] * cs;
+                    s.vy[k] = sp[k] * sn;
+                }
+            }
+        }
+        /* ---- ownship (wave-uniform), :73-89: speed first, then heading */
+        if (!odd) {
+            mcts_normals(rng, fp, UAM_MPH_OWN_H, 0, zh0, zh1);
+            if (p.speed_sigma != 0.0) mcts_normals(rng, fp, UAM_MPH_OWN_S, 0, zs0, zs1);
+        }
+        s.osp += accel;
+        s.osp = fmax(p.min_speed, fmin(s.osp, p.max_speed));
+        s.osp += 0.0 + p.speed_sigma * (odd ? zs1 : zs0);
+        s.ohd += d_heading;
+        s.ohd += 0.0 + p.heading_sigma * (odd ? zh1 : zh0);
+        double sn, cs;
+        uam_sincos(s.ohd, &sn, &cs);
+        s.ovx = s.osp * cs;
+        s.ovy = s.osp * sn;
+        s.ox += s.ovx;
+        s.oy += s.ovy;
+        if (!(0.0 < s.ox && s.ox < p.W) || !(0.0 < s.oy && s.oy < p.H)) { flags = 1u; break; }      /* :94-96 */
+        /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
+        bool near = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int i = lane + 64 * k;
+            const double dx = s.x[k] - s.ox, dy = s.y[k] - s.oy;
+            near = near || (i < p.N && (dx * dx + dy * dy) < p.sep2);
+        }
+        if (__any(near)) { flags = 2u; break; }
+        const double gdx = s.ox - gx, gdy = s.oy - gy;
+        if ((gdx * gdx + gdy * gdy) < p.sep2) { flags = 4u; break; }                                   /* :109-112 */
+    }
+    return flags;
+}
+
+/* SingleAircraftState.reward, :25-32 */
+__device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const MctsState& s, double gx, double gy, uint32_t flags)
+{
+    if (flags & 3u) return 0.0;
+    if (flags & 4u) return 1.0;
+    const double dx = s.ox - gx, dy = s.oy - gy;
+    return 1 - __builtin_sqrt(dx * dx + dy * dy) / p.reward_div;
+}
+
+template <int K>
+__device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const double* root, int lane, MctsState& s, double* sp,
+                                               double& gx, double& gy)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = lane + 64 * k;
+        const bool ok = i < p.N;
+        const double* it = root + 6 * (size_t)(ok ? i : 0);
+        s.x[k] = ok ? it[0] : 0.0; s.y[k] = ok ? it[1] : 0.0; s.vx[k] = ok ? it[2] : 0.0; s.vy[k] = ok ? it[3] : 0.0;
+        sp[k] = ok ? it[4] : 0.0; s.hd[k] = ok ? it[5] : 0.0;
+    }
+    const double* own = root + 6 * (size_t)p.N;
+    s.ox = own[0]; s.oy = own[1]; s.ovx = own[2]; s.ovy = own[3]; s.osp = own[4]; s.ohd = own[5];
+    gx = own[6]; gy = own[7];
+}
+
+template <int K>
+__device__ __forceinline__ void mcts_store_node(const UamMctsParams& p, double* pint, double* pown, int node, int lane,
+                                                const MctsState& s)
+{
+    double* b = pint + (size_t)node * 5 * p.Npad;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = lane + 64 * k;
+        if (i < p.Npad) {
+            b[i] = s.x[k]; b[p.Npad + i] = s.y[k]; b[2 * p.Npad + i] = s.vx[k]; b[3 * p.Npad + i] = s.vy[k];
+            b[4 * p.Npad + i] = s.hd[k];
+        }
+    }
+    if (lane < 6) {
+        const double v = lane == 0 ? s.ox : lane == 1 ? s.oy : lane == 2 ? s.ovx : lane == 3 ? s.ovy : lane == 4 ? s.osp : s.ohd;
+        pown[(size_t)node * 8 + lane] = v;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const double* pint, const double* pown, int node,
+                                               int lane, MctsState& s)
+{
+    const double* b = pint + (size_t)node * 5 * p.Npad;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = lane + 64 * k;
+        const bool ok = i < p.Npad;
+        const int j = ok ? i : 0;
+        s.x[k] = b[j]; s.y[k] = b[p.Npad + j]; s.vx[k] = b[2 * p.Npad + j]; s.vy[k] = b[3 * p.Npad + j];
+        s.hd[k] = b[4 * p.Npad + j];
+    }
+    const double* o = pown + (size_t)node * 8;
+    s.ox = o[0]; s.oy = o[1]; s.ovx = o[2]; s.ovy = o[3]; s.osp = o[4]; s.ohd = o[5];
+}
+
+/* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
+template <int K>
+__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search_kernel(const UamMctsParams p)
+{
+    __shared__ MctsTree trees[UAM_MCTS_WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
+    if (root >= p.B) return;
+    MctsTree& t = trees[wv];
+    double* pint = p.pool_int + (size_t)root * p.cap * 5 * p.Npad;
+    double* pown = p.pool_own + (size_t)root * p.cap * 8;
+
+    MctsState rs;
+    double sp[K];
+    double gx, gy;
+    mcts_load_root<K>(p, p.roots + (size_t)root * (6 * p.N + 8), lane, rs, sp, gx, gy);
+    mcts_store_node<K>(p, pint, pown, 0, lane, rs);
+    for (int i = lane; i < p.cap; i += 64) {
+        t.n[i] = 0.0; t.q[i] = 0.0; t.rew[i] = 0.0;
+        t.parent[i] = 255; t.nchild[i] = 0; t.depth[i] = 0; t.term[i] = 0; t.act[i] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (p.depth == 0) t.term[0] = 1;
+
+    MctsRng rng;
+    rng.root = p.root_id0 + (uint32_t)root; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+    int nn = 1;
+    for (int sim = 0; sim < p.sims; sim++) {
+        rng.sim = (uint32_t)sim; rng.mv = 0;
+        /* ---- tree_policy */
+        int v = 0;
+        bool have_state = false;
+        uint32_t flags = 0;
+        int depth = 0;
+        MctsState s;
+        while (!t.term[v]) {
+            const int nc = t.nchild[v];
+            if (nc < 9) {
+                /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
+                const int k = 8 - nc;
+                mcts_load_node<K>(p, pint, pown, v, lane, s);
+                flags = mcts_move<K>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s);
+                rng.mv = 1;
+                const int c = nn++;
+                depth = t.depth[v] + 1;
+                const bool term = flags != 0 || depth == p.depth;
+                t.parent[c] = (uint8_t)v; t.depth[c] = (uint8_t)depth; t.act[c] = (uint8_t)k; t.term[c] = term ? 1 : 0;
+                t.child[v][nc] = (uint8_t)c;
+                t.nchild[v] = (uint8_t)(nc + 1);
+                if (term) t.rew[c] = mcts_reward(p, s, gx, gy, flags);
+                else mcts_store_node<K>(p, pint, pown, c, lane, s);     /* only expandable nodes keep their state */
+                v = c;
+                have_state = true;
+                break;
+            }
+            /* best_child(c_param), common.py:47-52: lanes 0..8 weigh one child each, first maximum wins */
+            const double logn = uam_log(t.n[v]);
+            double w = -1.0e300;
+            if (lane < 9) {
+                const int c = t.child[v][lane];
+                const double cn = t.n[c];
+                w = (t.q[c] / cn) + p.c_param * __builtin_sqrt((2 * logn / cn));
+            }
+            int best = lane;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const double w2 = __shfl_xor(w, o);
+                const int b2 = __shfl_xor(best, o);
+                if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
+            }
+            best = __shfl(best, 0);
+            v = t.child[v][best];
+        }
+        /* ---- rollout, nodes_single_randintru.py:212-218 */
+        double r;
+        if (t.term[v]) {
+            r = t.rew[v];
+        } else {
+            (void)have_state;
+            while (flags == 0 && depth < p.depth) {
+                uint32_t w4[4];
+                mcts_philox(rng, 0, UAM_MPH_ACTION, 0, w4);
+                const int a = (int)(((uint64_t)w4[0] * 9u) >> 32);          /* rollout_policy */
+                flags = mcts_move<K>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s);
+                rng.mv++;
+                depth++;
+            }
+            r = mcts_reward(p, s, gx, gy, flags);
+        }
+        /* ---- backpropagate (every lane writes the same values: wave-uniform LDS update) */
+        for (int u = v; u != 255; u = t.parent[u]) { t.n[u] += 1.; t.q[u] += r; }
+    }
+    /* best_child(c_param = 0.) of the root */
+    {
+        double w = -1.0e300;
+        const int nc = t.nchild[0];
+        const double logn = uam_log(t.n[0]);
+        if (lane < nc) {
+            const int c = t.child[0][lane];
+            const double cn = t.n[c];
+            w = (t.q[c] / cn) + 0. * __builtin_sqrt((2 * logn / cn));
+        }
+        int best = lane;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const double w2 = __shfl_xor(w, o);
+            const int b2 = __shfl_xor(best, o);
+            if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
+        }
+        best = __shfl(best, 0);
+        if (lane == 0) {
+            const int k = nc > 0 ? t.act[t.child[0][best]] : 4;
+            p.actions_out[2 * (size_t)root] = k / 3;
+            p.actions_out[2 * (size_t)root + 1] = k % 3;
+        }
+        if (lane < 9) {
+            const bool has = lane < nc;
+            const int c = has ? t.child[0][lane] : 0;
+            if (p.child_q_out) p.child_q_out[9 * (size_t)root + lane] = has ? t.q[c] : 0.0;
+            if (p.child_n_out) p.child_n_out[9 * (size_t)root + lane] = has ? t.n[c] : 0.0;
+        }
+    }
+}
+
+/* one move() per state, no tree: parity / building block */
+template <int K>
+__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_kernel(const UamMctsParams p)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
+    if (root >= p.B) return;
+    MctsState s;
+    double sp[K];
+    double gx, gy;
+    const size_t len = 6 * (size_t)p.N + 8;
+    mcts_load_root<K>(p, p.roots + (size_t)root * len, lane, s, sp, gx, gy);
+    MctsRng rng;
+    rng.root = p.root_id0 + (uint32_t)root; rng.sim = p.sim_index; rng.mv = p.move_index; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+    const int a0 = p.actions_in[2 * (size_t)root], a1 = p.actions_in[2 * (size_t)root + 1];
+    const uint32_t flags = mcts_move<K>(p, rng, lane, sp, gx, gy, a0, a1, s);
+    double* out = p.next_out + (size_t)root * len;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int i = lane + 64 * k;
+        if (i < p.N) {
+            double* it = out + 6 * (size_t)i;
+            it[0] = s.x[k]; it[1] = s.y[k]; it[2] = s.vx[k]; it[3] = s.vy[k]; it[4] = sp[k]; it[5] = s.hd[k];
+        }
+    }
+    if (lane == 0) {
+        double* own = out + 6 * (size_t)p.N;
+        own[0] = s.ox; own[1] = s.oy; own[2] = s.ovx; own[3] = s.ovy; own[4] = s.osp; own[5] = s.ohd; own[6] = gx; own[7] = gy;
+        p.flags_out[3 * (size_t)root] = (flags & 1u) ? 1 : 0;
+        p.flags_out[3 * (size_t)root + 1] = (flags & 2u) ? 1 : 0;
+        p.flags_out[3 * (size_t)root + 2] = (flags & 4u) ? 1 : 0;
+        p.reward_out[root] = mcts_reward(p, s, gx, gy, flags);
+    }
+}
+
+/* RAW6 root states straight from a RandIntruder env handle's SoA state (float64, no obs rounding) */
+template <bool POS64>
+__global__ void uam_mcts_roots_kernel(const UamParams p, double* out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = p.N + 1;
+    if (t >= p.B * per) return;
+    const int e = t / per, i = t - e * per;
+    double* row = out + (size_t)e * (6 * p.N + 8);
+    if (i < p.N) {
+        const size_t k = (size_t)e * p.Np + i;
+        double* it = row + 6 * (size_t)i;
+        it[0] = POS64 ? ((const double*)p.s.px)[k] : (double)((const float*)p.s.px)[k];
+        it[1] = POS64 ? ((const double*)p.s.py)[k] : (double)((const float*)p.s.py)[k];
+        it[2] = (double)p.s.vx[k]; it[3] = (double)p.s.vy[k];
+        it[4] = p.s.isp[k]; it[5] = p.s.ihd[k];
+    } else {
+        double* own = row + 6 * (size_t)p.N;
+        own[0] = (double)p.s.own_x[e]; own[1] = (double)p.s.own_y[e]; own[2] = p.s.own_vx[e]; own[3] = p.s.own_vy[e];
+        own[4] = p.s.own_s[e]; own[5] = p.s.own_h[e]; own[6] = p.s.goal_x[e]; own[7] = p.s.goal_y[e];
+    }
+}
+
+#endif /* UAM_MCTS_DEVICE_H */

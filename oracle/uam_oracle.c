@@ -759,7 +759,9 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
  * common.py (MCTSNode.best_child, rollout_policy) and search_single.py (MCTS.best_action, tree_policy).
  * Third-party arithmetic: NumPy scalar `x**2` is libm pow(x, 2.0) (differs from x*x by 1 ulp in ~0.09 %
  * of cases, probed); legacy RandomState.randint(9) = masked rejection on one 32-bit word per attempt. */
-enum { MPH_HEADCHG = 1, MPH_OWN = 2, MPH_POS = 3, MPH_ACTION = 4 };
+/* Philox purposes; HEADCHG and the ownship noises are drawn per FRAME PAIR (counter word 2 carries frame>>1,
+ * the frame's parity selects the half of the block) */
+enum { MPH_HEADCHG = 1, MPH_OWN_H = 2, MPH_POS = 3, MPH_ACTION = 4, MPH_OWN_S = 5 };
 
 typedef struct {
     const uam_mcts_config* c;
@@ -847,9 +849,9 @@ static void mcts_move(mcts_ctx* m, const double* s_in, int a0, int a1, double* s
                 it[0] += vx + nx_;
                 it[1] += vy + ny_;
                 uint32_t w[4];
-                mphilox(m, (uint32_t)f, MPH_HEADCHG, (uint32_t)i, w);
-                p = u32d(w[0]);
-                ud = u32d(w[1]);
+                mphilox(m, (uint32_t)f >> 1, MPH_HEADCHG, (uint32_t)i, w);
+                p = u32d(w[2 * (f & 1)]);
+                ud = u32d(w[2 * (f & 1) + 1]);
             }
             if (p < c->heading_change_prob) {                                 /* :64-70 */
                 double deg = -c->heading_change_max_deg + (c->heading_change_max_deg - (-c->heading_change_max_deg)) * ud;
@@ -869,7 +871,11 @@ static void mcts_move(mcts_ctx* m, const double* s_in, int a0, int a1, double* s
             zh = mt_gauss(&m->fake, &m->mt);
             own[5] += 0.0 + c->heading_sigma * zh;
         } else {
-            mphilox_normals(m, (uint32_t)f, MPH_OWN, 0, &zs, &zh);
+            double z0, z1;
+            zs = 0.0;
+            if (c->speed_sigma != 0.0) { mphilox_normals(m, (uint32_t)f >> 1, MPH_OWN_S, 0, &z0, &z1); zs = (f & 1) ? z1 : z0; }
+            mphilox_normals(m, (uint32_t)f >> 1, MPH_OWN_H, 0, &z0, &z1);
+            zh = (f & 1) ? z1 : z0;
             own[4] += accel;
             own[4] = fmax(c->min_speed, fmin(own[4], c->max_speed));
             own[4] += 0.0 + c->speed_sigma * zs;

@@ -1,0 +1,120 @@
+"""Batched MCTS on the GPU (through the C-ABI) against the CPU oracle on the same inputs: the oracle's
+MT19937/libm mode is pinned bit-exactly to the reference (tests/test_oracle_mcts_golden.py); here its
+Philox/portable-math mode must agree with the HIP kernels to the bit — next states, flags, rewards, the
+chosen action and the root children's (q, n)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def uamenv():
+    import torch
+    assert torch.cuda.is_available()
+    import uamenv as m
+    m._capi.lib()
+    return m
+
+
+def _ocfg(oracle, cfg):
+    o = oracle.UamMctsConfig()
+    for name, _ in oracle.UamMctsConfig._fields_:
+        setattr(o, name, getattr(cfg, name))
+    return o
+
+
+def _roots(name, extra_noise=0):
+    fx = gu.load(name)
+    roots = np.unique(fx["states"], axis=0)
+    return np.ascontiguousarray(roots)
+
+
+@pytest.mark.parametrize("name,over", [("g11_mcts_move_n8", {}), ("g11_mcts_move_n20", {}), ("g11_mcts_move_n8_flags", {}),
+                                       ("g11_mcts_move_n8", dict(position_sigma=10 / 30, speed_sigma=2 / 30))])
+def test_move_matches_oracle_bit_exact(uamenv, oracle, name, over):
+    roots = _roots(name)
+    N = (roots.shape[1] - 8) // 6
+    planner = uamenv.BatchedMCTS(N, seed=99, **over)
+    ocfg = _ocfg(oracle, planner.cfg)
+    states = np.repeat(roots, 9, axis=0)
+    actions = np.tile(np.array([(a, b) for a in range(3) for b in range(3)], dtype=np.int32), (len(roots), 1))
+    nxt, flags, rew = planner.move(states, actions, root_id0=40, sim=7, move=2)
+    nxt, flags, rew = nxt.cpu().numpy(), flags.cpu().numpy(), rew.cpu().numpy()
+    seen = np.zeros(3, int)
+    for k in range(len(states)):
+        on, of, orw, _ = oracle.mcts_move(ocfg, states[k], actions[k], rng_mode=oracle.RNG_PHILOX,
+                                         math_impl=oracle.MATH_PORTABLE, root_id=40 + k, sim=7, move=2)
+        assert np.array_equal(flags[k], of), (k, flags[k], of)
+        assert np.array_equal(nxt[k], on), (k, np.abs(nxt[k] - on).max())
+        assert rew[k] == orw
+        seen += of
+    if name.endswith("flags"):
+        assert seen.min() > 0
+
+
+@pytest.mark.parametrize("name,sims,depth", [("g12_mcts_search_n8", 100, 3), ("g12_mcts_search_n20", 100, 3),
+                                             ("g12_mcts_search_n8_flags", 100, 3), ("g12_mcts_search_n8", 40, 2),
+                                             ("g12_mcts_search_n8", 254, 4)])
+def test_best_action_matches_oracle_bit_exact(uamenv, oracle, name, sims, depth):
+    roots = gu.load(name)["states"]
+    N = (roots.shape[1] - 8) // 6
+    planner = uamenv.BatchedMCTS(N, seed=5, simulations=sims, search_depth=depth)
+    ocfg = _ocfg(oracle, planner.cfg)
+    acts, cq, cn = planner.best_action(roots, root_id0=1000, want_children=True)
+    acts, cq, cn = acts.cpu().numpy(), cq.cpu().numpy(), cn.cpu().numpy()
+    for k in range(len(roots)):
+        o = oracle.mcts_best_action(ocfg, roots[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE,
+                                    root_id=1000 + k)
+        assert np.array_equal(cn[k], o["child_n"]), (k, cn[k], o["child_n"])
+        assert np.array_equal(cq[k], o["child_q"]), (k, cq[k] - o["child_q"])
+        assert np.array_equal(acts[k], o["best_action"]), (k, acts[k], o["best_action"])
+
+
+def test_bad_mcts_config_is_rejected(uamenv):
+    with pytest.raises(uamenv.UamError):
+        uamenv.BatchedMCTS(8, simulations=255).best_action(np.zeros((1, 56)))
+    with pytest.raises(uamenv.UamError):
+        uamenv.BatchedMCTS(300).best_action(np.zeros((1, 6 * 300 + 8)))
+    with pytest.raises(ValueError):
+        uamenv.BatchedMCTS(8).best_action(np.zeros((1, 40)))
+
+
+def test_many_intruders_and_batch_invariance(uamenv, oracle):
+    """N=150 (3 intruders per lane) against the oracle; and a root's result must not depend on its batch."""
+    rs = np.random.RandomState(3)
+    N, B = 150, 6
+    roots = np.zeros((B, 6 * N + 8))
+    for b in range(B):
+        hd = rs.uniform(0, 2 * np.pi, N)
+        sp = rs.uniform(5 / 3, 8 / 3, N)
+        it = np.stack([rs.uniform(0, 800, N), rs.uniform(0, 800, N), sp * np.cos(hd), sp * np.sin(hd), sp, hd], axis=1)
+        roots[b, :6 * N] = it.ravel()
+        roots[b, 6 * N:] = [400, 400, 1.2, 1.2, 1.7, np.pi / 4, rs.uniform(0, 800), rs.uniform(0, 800)]
+    planner = uamenv.BatchedMCTS(N, seed=8, simulations=30, search_depth=2)
+    ocfg = _ocfg(oracle, planner.cfg)
+    acts, cq, cn = planner.best_action(roots, root_id0=0, want_children=True)
+    for k in range(B):
+        o = oracle.mcts_best_action(ocfg, roots[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE, root_id=k)
+        assert np.array_equal(cq[k].cpu().numpy(), o["child_q"]) and np.array_equal(acts[k].cpu().numpy(), o["best_action"])
+    a2, q2, n2 = planner.best_action(roots[3:5], root_id0=3, want_children=True)
+    assert np.array_equal(q2.cpu().numpy(), cq[3:5].cpu().numpy())
+
+
+def test_roots_from_env_feed_the_planner(uamenv):
+    """Agent_RandInt.py loop shape: env obs -> root state -> best action -> env.step, all on the device."""
+    import torch
+    B, N = 64, 8
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=2)
+    obs = env.reset()
+    planner = uamenv.BatchedMCTS(N, seed=2, simulations=30)
+    roots = planner.roots_from_env(env)
+    assert roots.shape == (B, 6 * N + 8) and roots.dtype == torch.float64
+    assert torch.allclose(roots.float(), obs, atol=1e-4)       # same numbers as the raw observation
+    for t in range(3):
+        acts = planner.best_action(planner.roots_from_env(env), root_id0=t * B)
+        assert bool(((acts >= 0) & (acts <= 2)).all())
+        env.step(acts)
+    env.close()
