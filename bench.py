@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--intruders", type=int, default=N_INTRUDERS)
     ap.add_argument("--policy", default="random", choices=["random", "goal"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets 2 ranks share one GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--variant", default="discrete9", help="exploration only: env variant (default = the BASELINE workload)")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
@@ -87,12 +89,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     B, N = args.batch, args.intruders
     env = uamenv.BatchedSingleAircraftEnv(B, N, variant=args.variant, rng=args.rng, precision=args.precision, seed=0,

@@ -29,6 +29,11 @@
 #define UAM_MCTS_MAX_NODES 256          /* simulations + 1 <= 256 (node ids are bytes) */
 #define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
 #define UAM_MCTS_WAVES_PER_BLOCK 2
+#ifndef UAM_MCTS_WAVES_PER_EU
+#define UAM_MCTS_BOUNDS __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK)
+#else
+#define UAM_MCTS_BOUNDS __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_MCTS_WAVES_PER_EU, 8)))
+#endif
 
 enum { UAM_MPH_HEADCHG = 1, UAM_MPH_OWN_H = 2, UAM_MPH_POS = 3, UAM_MPH_ACTION = 4, UAM_MPH_OWN_S = 5 };
 
@@ -58,10 +63,9 @@ struct MctsTree {
     uint8_t child[UAM_MCTS_MAX_NODES][9];
 };
 
-/* the state vector of one node, distributed over the wave */
-struct MctsState {
-    double x[UAM_MCTS_MAX_SLOTS], y[UAM_MCTS_MAX_SLOTS], vx[UAM_MCTS_MAX_SLOTS], vy[UAM_MCTS_MAX_SLOTS],
-        hd[UAM_MCTS_MAX_SLOTS];
+/* the state vector of one node, distributed over the wave (K intruders per lane) */
+template <int K> struct MctsState {
+    double x[K], y[K], vx[K], vy[K], hd[K];
     double ox, oy, ovx, ovy, osp, ohd;   /* ownship: wave-uniform */
 };
 
@@ -86,17 +90,61 @@ __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepai
 }
 
 /* SingleAircraftState.move, nodes_single_randintru.py:39-114.  `sp` = per-slot intruder speed (constant
- * over the tree).  Returns flag bits: 1 hit_wall, 2 conflict, 4 reach_goal. */
+ * over the tree).  Returns flag bits: 1 hit_wall, 2 conflict, 4 reach_goal.
+ *
+ * The ownship's trajectory over the move's frames does not depend on the intruders, so it is computed
+ * up front with the frames spread over lanes: the Box-Muller pairs (lane j = frame pair j) and the
+ * sincos of every frame's heading (lane f = frame f) are evaluated ONCE in parallel instead of once per
+ * frame wave-uniformly.  The recurrences themselves (speed clamp, heading, position sums) run in the
+ * reference's order, sequentially, so every rounding is the reference's.  Needs frames <= 64. */
 template <int K>
 __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
-                                     const double gx, const double gy, const int a0, const int a1, MctsState& s)
+                                     const double gx, const double gy, const int a0, const int a1, MctsState<K>& s)
 {
+    const int F = p.frames;
     const double d_heading = (double)(a0 - 1) * p.d_heading;
     const double accel = (double)(a1 - 1) * p.d_speed;
+    /* ---- ownship noise: one Box-Muller pair per frame pair, :75,:78 */
+    double zhp0 = 0.0, zhp1 = 0.0, zsp0 = 0.0, zsp1 = 0.0;
+    if (lane < ((F + 1) >> 1)) {
+        mcts_normals(rng, (uint32_t)lane, UAM_MPH_OWN_H, 0, zhp0, zhp1);
+        if (p.speed_sigma != 0.0) mcts_normals(rng, (uint32_t)lane, UAM_MPH_OWN_S, 0, zsp0, zsp1);
+    }
+    const int src = lane >> 1;
+    const double zha = __shfl(zhp0, src), zhb = __shfl(zhp1, src), zsa = __shfl(zsp0, src), zsb = __shfl(zsp1, src);
+    const double zh = (lane & 1) ? zhb : zha, zs = (lane & 1) ? zsb : zsa;      /* lane f holds frame f's noise */
+    /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
+    double spd = s.osp, hdg = s.ohd, my_sp = 0.0, my_hd = 0.0;
+    for (int f = 0; f < F; f++) {
+        const double zsf = __shfl(zs, f), zhf = __shfl(zh, f);
+        spd += accel;
+        spd = fmax(p.min_speed, fmin(spd, p.max_speed));
+        spd += 0.0 + p.speed_sigma * zsf;
+        hdg += d_heading;
+        hdg += 0.0 + p.heading_sigma * zhf;
+        if (lane == f) { my_sp = spd; my_hd = hdg; }
+    }
+    /* ---- every frame's velocity at once, :81-82 */
+    double sn, cs;
+    uam_sincos(my_hd, &sn, &cs);
+    const double my_vx = my_sp * cs, my_vy = my_sp * sn;
+    /* ---- positions in frame order, :83-86 */
+    double ox = s.ox, oy = s.oy, my_ox = 0.0, my_oy = 0.0;
+    for (int f = 0; f < F; f++) {
+        ox += __shfl(my_vx, f);
+        oy += __shfl(my_vy, f);
+        if (lane == f) { my_ox = ox; my_oy = oy; }
+    }
+    const bool in_f = lane < F;
+    const bool wall = !(0.0 < my_ox && my_ox < p.W) || !(0.0 < my_oy && my_oy < p.H);
+    const double gdx = my_ox - gx, gdy = my_oy - gy;
+    const unsigned long long wallm = __ballot(in_f && wall);
+    const unsigned long long goalm = __ballot(in_f && (gdx * gdx + gdy * gdy) < p.sep2);
+
     uint32_t flags = 0;
-    double zh0 = 0.0, zh1 = 0.0, zs0 = 0.0, zs1 = 0.0;
+    int fe = F - 1;
     uint32_t hw[K][4];
-    for (int f = 0; f < p.frames; f++) {
+    for (int f = 0; f < F; f++) {
         const uint32_t fp = (uint32_t)f >> 1;
         const int odd = f & 1;
         /* ---- intruders: position += velocity (+ noise), Bernoulli heading change, :54-70 */
@@ -119,47 +167,35 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                     const double ud = uam_u32d(odd ? hw[k][3] : hw[k][1]);
                     const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
                     s.hd[k] += deg * UAM_DEG2RAD;
-                    double sn, cs;
-                    uam_sincos(s.hd[k], &sn, &cs);
-                    s.vx[k] = sp[k] * cs;
-                    s.vy[k] = sp[k] * sn;
+                    double isn, ics;
+                    uam_sincos(s.hd[k], &isn, &ics);
+                    s.vx[k] = sp[k] * ics;
+                    s.vy[k] = sp[k] * isn;
                 }
             }
         }
-        /* ---- ownship (wave-uniform), :73-89: speed first, then heading */
-        if (!odd) {
-            mcts_normals(rng, fp, UAM_MPH_OWN_H, 0, zh0, zh1);
-            if (p.speed_sigma != 0.0) mcts_normals(rng, fp, UAM_MPH_OWN_S, 0, zs0, zs1);
-        }
-        s.osp += accel;
-        s.osp = fmax(p.min_speed, fmin(s.osp, p.max_speed));
-        s.osp += 0.0 + p.speed_sigma * (odd ? zs1 : zs0);
-        s.ohd += d_heading;
-        s.ohd += 0.0 + p.heading_sigma * (odd ? zh1 : zh0);
-        double sn, cs;
-        uam_sincos(s.ohd, &sn, &cs);
-        s.ovx = s.osp * cs;
-        s.ovy = s.osp * sn;
-        s.ox += s.ovx;
-        s.oy += s.ovy;
-        if (!(0.0 < s.ox && s.ox < p.W) || !(0.0 < s.oy && s.oy < p.H)) { flags = 1u; break; }      /* :94-96 */
+        if ((wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                        /* :94-96 */
         /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
+        const double oxf = __shfl(my_ox, f), oyf = __shfl(my_oy, f);
         bool near = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int i = lane + 64 * k;
-            const double dx = s.x[k] - s.ox, dy = s.y[k] - s.oy;
+            const double dx = s.x[k] - oxf, dy = s.y[k] - oyf;
             near = near || (i < p.N && (dx * dx + dy * dy) < p.sep2);
         }
-        if (__any(near)) { flags = 2u; break; }
-        const double gdx = s.ox - gx, gdy = s.oy - gy;
-        if ((gdx * gdx + gdy * gdy) < p.sep2) { flags = 4u; break; }                                   /* :109-112 */
+        if (__any(near)) { flags = 2u; fe = f; break; }
+        if ((goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                        /* :109-112 */
     }
+    s.ox = __shfl(my_ox, fe); s.oy = __shfl(my_oy, fe);
+    s.ovx = __shfl(my_vx, fe); s.ovy = __shfl(my_vy, fe);
+    s.osp = __shfl(my_sp, fe); s.ohd = __shfl(my_hd, fe);
     return flags;
 }
 
 /* SingleAircraftState.reward, :25-32 */
-__device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const MctsState& s, double gx, double gy, uint32_t flags)
+template <int K>
+__device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const MctsState<K>& s, double gx, double gy, uint32_t flags)
 {
     if (flags & 3u) return 0.0;
     if (flags & 4u) return 1.0;
@@ -168,7 +204,7 @@ __device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const Mcts
 }
 
 template <int K>
-__device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const double* root, int lane, MctsState& s, double* sp,
+__device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const double* root, int lane, MctsState<K>& s, double* sp,
                                                double& gx, double& gy)
 {
 #pragma unroll
@@ -186,7 +222,7 @@ __device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const dou
 
 template <int K>
 __device__ __forceinline__ void mcts_store_node(const UamMctsParams& p, double* pint, double* pown, int node, int lane,
-                                                const MctsState& s)
+                                                const MctsState<K>& s)
 {
     double* b = pint + (size_t)node * 5 * p.Npad;
 #pragma unroll
@@ -205,7 +241,7 @@ __device__ __forceinline__ void mcts_store_node(const UamMctsParams& p, double* 
 
 template <int K>
 __device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const double* pint, const double* pown, int node,
-                                               int lane, MctsState& s)
+                                               int lane, MctsState<K>& s)
 {
     const double* b = pint + (size_t)node * 5 * p.Npad;
 #pragma unroll
@@ -222,7 +258,7 @@ __device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const dou
 
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
 template <int K>
-__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search_kernel(const UamMctsParams p)
+__global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree trees[UAM_MCTS_WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -232,7 +268,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search
     double* pint = p.pool_int + (size_t)root * p.cap * 5 * p.Npad;
     double* pown = p.pool_own + (size_t)root * p.cap * 8;
 
-    MctsState rs;
+    MctsState<K> rs;
     double sp[K];
     double gx, gy;
     mcts_load_root<K>(p, p.roots + (size_t)root * (6 * p.N + 8), lane, rs, sp, gx, gy);
@@ -256,7 +292,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search
         bool have_state = false;
         uint32_t flags = 0;
         int depth = 0;
-        MctsState s;
+        MctsState<K> s;
         while (!t.term[v]) {
             const int nc = t.nchild[v];
             if (nc < 9) {
@@ -271,7 +307,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search
                 t.parent[c] = (uint8_t)v; t.depth[c] = (uint8_t)depth; t.act[c] = (uint8_t)k; t.term[c] = term ? 1 : 0;
                 t.child[v][nc] = (uint8_t)c;
                 t.nchild[v] = (uint8_t)(nc + 1);
-                if (term) t.rew[c] = mcts_reward(p, s, gx, gy, flags);
+                if (term) t.rew[c] = mcts_reward<K>(p, s, gx, gy, flags);
                 else mcts_store_node<K>(p, pint, pown, c, lane, s);     /* only expandable nodes keep their state */
                 v = c;
                 have_state = true;
@@ -309,7 +345,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_search
                 rng.mv++;
                 depth++;
             }
-            r = mcts_reward(p, s, gx, gy, flags);
+            r = mcts_reward<K>(p, s, gx, gy, flags);
         }
         /* ---- backpropagate (every lane writes the same values: wave-uniform LDS update) */
         for (int u = v; u != 255; u = t.parent[u]) { t.n[u] += 1.; t.q[u] += r; }
@@ -353,7 +389,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
     if (root >= p.B) return;
-    MctsState s;
+    MctsState<K> s;
     double sp[K];
     double gx, gy;
     const size_t len = 6 * (size_t)p.N + 8;
@@ -377,7 +413,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
         p.flags_out[3 * (size_t)root] = (flags & 1u) ? 1 : 0;
         p.flags_out[3 * (size_t)root + 1] = (flags & 2u) ? 1 : 0;
         p.flags_out[3 * (size_t)root + 2] = (flags & 4u) ? 1 : 0;
-        p.reward_out[root] = mcts_reward(p, s, gx, gy, flags);
+        p.reward_out[root] = mcts_reward<K>(p, s, gx, gy, flags);
     }
 }
 
