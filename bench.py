@@ -128,11 +128,10 @@ def main():
                 a = env.policy_actions("goal", out=acts)
             else:
                 a = tape[i % TAPE_LEN]
-            obs, rew, done, _ = env.step(a)
+            # rewards/dones land directly in row j of the chunk slab: identical per-step work at every N
+            j = i % GATHER_EVERY
+            env.step_into(a, rew_slab[j], done_slab[j])
             if world > 1:
-                j = i % GATHER_EVERY
-                rew_slab[j].copy_(rew)
-                done_slab[j].copy_(env._done)
                 if j == GATHER_EVERY - 1:
                     # the one exchange of the path: reward/done slabs of the chunk, gathered over xGMI
                     dist.all_gather_into_tensor(rew_all, rew_slab)

@@ -208,6 +208,19 @@ class BatchedSingleAircraftEnv:
                                       self._done.data_ptr(), self._info.data_ptr(), self._stream()))
         self._pending = a   # keep the action buffer alive until the kernel has consumed it
 
+    def step_into(self, actions, rew_out, done_out):
+        """`step` that writes rewards (float32[B]) and dones (uint8[B]) straight into caller-owned device
+        rows, e.g. row k of a [K, B] rollout slab that is gathered across GPUs once per chunk."""
+        torch = self._torch
+        a = self._as_actions(actions)
+        if rew_out.dtype != torch.float32 or done_out.dtype != torch.uint8 or rew_out.numel() != self.num_envs \
+                or done_out.numel() != self.num_envs or not (rew_out.is_contiguous() and done_out.is_contiguous()):
+            raise ValueError("rew_out must be contiguous float32[B] and done_out contiguous uint8[B]")
+        capi.check(self._lib.uam_step(self._h, a.data_ptr(), self._obs.data_ptr(), rew_out.data_ptr(),
+                                      done_out.data_ptr(), self._info.data_ptr(), self._stream()))
+        self._keep = a
+        return self._obs
+
     def step_wait(self):
         if self._pending is None:
             raise RuntimeError("not running an async step")
