@@ -33,7 +33,7 @@ class UamConfig(C.Structure):
         ("struct_size", C.c_uint32), ("num_envs", C.c_int32), ("num_intruders", C.c_int32),
         ("obs_mode", C.c_int32), ("action_mode", C.c_int32), ("dynamics", C.c_int32),
         ("rng_mode", C.c_int32), ("precision", C.c_int32), ("auto_reset", C.c_int32),
-        ("sparse_reward", C.c_int32), ("random_own_start", C.c_int32), ("reserved0", C.c_int32),
+        ("sparse_reward", C.c_int32), ("random_own_start", C.c_int32), ("track_episodes", C.c_int32),
         ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
         ("window_width", C.c_double), ("window_height", C.c_double),
         ("minimum_separation", C.c_double), ("nmac_dist", C.c_double),
@@ -106,6 +106,7 @@ SYMBOLS = [
     ("uam_step_many", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
+    ("uam_episode_stats", C.c_int, [_P, _P, _P, _P]),
     ("uam_get_state", C.c_int, [_P, C.POINTER(UamStateView)]),
     ("uam_set_state", C.c_int, [_P, C.POINTER(UamStateView)]),
     ("uam_policy", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P]),

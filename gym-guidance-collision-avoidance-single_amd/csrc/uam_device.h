@@ -69,6 +69,10 @@ struct UamDev {
     int32_t* no_conflict;
     uint32_t* reset_count; /* [B] episodes started so far: Philox counter of the reset draws */
     float4*  share;     /* [B*3] OwnShare records handed from uam_own_kernel to uam_sweep_kernel */
+    double*  ep_ret;    /* [B] running episode return / length and those of the last finished episode */
+    int32_t* ep_len;
+    double*  ep_last_ret;
+    int32_t* ep_last_len;
     uint32_t* mt_key;   /* [B*624] */
     int32_t* mt_pos;    /* [B] next word to consume (624 = wrap first) */
     int32_t* mt_gen;    /* [B] words [0,gen) of the current round are already twisted */
@@ -91,7 +95,7 @@ struct UamParams {
     UamDev s;
     const UamCold* c;
     int B, N, Np, Q, L, lshift, E, D;
-    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec;
+    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep;
     uint32_t seed_lo, seed_hi, gid0;
     uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
     float W32, H32, vmax32, psig32;
@@ -933,6 +937,13 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p, const UamCol
         p.done[env] = done ? 1 : 0;
         if (p.info) p.info[env] = (uint8_t)info;
         if (!(done && p.auto_reset) && new_conf) p.s.no_conflict[env] += (int32_t)new_conf;
+        if (p.track_ep) {   /* Monitor.step, baselines/bench/monitor.py:58-75 */
+            const double r = p.s.ep_ret[env] + (double)reward;
+            const int32_t l = p.s.ep_len[env] + 1;
+            if (done) { p.s.ep_last_ret[env] = r; p.s.ep_last_len[env] = l; }
+            p.s.ep_ret[env] = done ? 0.0 : r;
+            p.s.ep_len[env] = done ? 0 : l;
+        }
     }
 
     /* ownship/goal part of the obs: lanes 0 and 1 of the group carry one float4 each */
@@ -989,6 +1000,7 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParam
         rng.load(p.s, env);
         reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail);
         if (gl == 0) rng.store(p.s, env);
+        if (gl == 0 && p.track_ep) { p.s.ep_ret[env] = 0.0; p.s.ep_len[env] = 0; }   /* Monitor.reset */
         if (quad_ok) {
             quad_store_pos<POS64, SH>(p, base, q);
             quad_store_vel<POS64, SH>(p, base, q);

@@ -190,6 +190,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->E = e->E; p->D = e->D;
     p->obs_mode = c.obs_mode; p->action_mode = c.action_mode; p->auto_reset = c.auto_reset;
     p->sparse_reward = c.sparse_reward;
+    p->track_ep = c.track_episodes ? 1 : 0;
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
@@ -290,6 +291,12 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.reset_count, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.share, (size_t)B * 3);
+    if (cfg->track_episodes) {
+        if (!rc) rc = dev_alloc(e, &e->s.ep_ret, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.ep_len, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.ep_last_ret, (size_t)B);
+        if (!rc) rc = dev_alloc(e, &e->s.ep_last_len, (size_t)B);
+    }
     e->cold = nullptr;
     if (!rc) rc = dev_alloc(e, &e->cold, (size_t)1);
     if (!rc) {
@@ -550,6 +557,17 @@ extern "C" int uam_counters(uam_env* e, int32_t* no_conflict_out_dev, void* stre
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(no_conflict_out_dev, e->s.no_conflict, (size_t)e->cfg.num_envs * 4, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
+    return UAM_OK;
+}
+
+extern "C" int uam_episode_stats(uam_env* e, double* ret_out_dev, int32_t* len_out_dev, void* stream)
+{
+    if (!e || !ret_out_dev || !len_out_dev) return fail(UAM_EINVAL, "NULL argument");
+    if (!e->cfg.track_episodes) return fail(UAM_EINVAL, "episode statistics need uam_config.track_episodes = 1");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t B = (size_t)e->cfg.num_envs;
+    HIP_TRY(hipMemcpyAsync(ret_out_dev, e->s.ep_last_ret, B * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(len_out_dev, e->s.ep_last_len, B * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return UAM_OK;
 }
 

@@ -98,10 +98,11 @@ def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox",
 class LazyInfos:
     """Sequence of `{'result': code}` dicts (SingleAircraftEnv.py:139) backed by the device code tensor."""
 
-    def __init__(self, codes, as_dict=True):
+    def __init__(self, codes, as_dict=True, episodes=None):
         self.codes = codes
         self._as_dict = as_dict
         self._host = None
+        self._episodes = episodes     # callable -> (done[B], return[B], length[B]) host arrays, or None
 
     def _h(self):
         if self._host is None:
@@ -113,7 +114,16 @@ class LazyInfos:
 
     def __getitem__(self, i):
         code = capi.INFO_CODES[int(self._h()[i])]
-        return {"result": code} if self._as_dict else code
+        if not self._as_dict:
+            return code
+        info = {"result": code}
+        if self._episodes is not None:
+            if callable(self._episodes):
+                self._episodes = self._episodes()
+            done, ret, ln = self._episodes
+            if done[i]:   # Monitor.step: info['episode'] = {'r','l','t'}, baselines/bench/monitor.py:68-74
+                info["episode"] = {"r": round(float(ret[i]), 6), "l": int(ln[i])}
+        return info
 
     def __iter__(self):
         for i in range(len(self)):
@@ -127,7 +137,7 @@ class BatchedSingleAircraftEnv:
     """B envs stepped by one fused HIP kernel per `step`; VecEnv-shaped."""
 
     def __init__(self, num_envs, num_intruders=None, variant="discrete9", rng="philox", precision="f32", seed=0,
-                 auto_reset=True, device=None, env_id_offset=0, config=Config, cfg=None, **overrides):
+                 auto_reset=True, device=None, env_id_offset=0, config=Config, cfg=None, monitor=False, **overrides):
         import torch
         self._torch = torch
         if not torch.cuda.is_available():
@@ -136,7 +146,9 @@ class BatchedSingleAircraftEnv:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
                                    (device if isinstance(device, int) else torch.device(device).index or 0))
         self.cfg = cfg if cfg is not None else make_config(
-            num_envs, num_intruders, variant, rng, precision, seed, auto_reset, env_id_offset, config, **overrides)
+            num_envs, num_intruders, variant, rng, precision, seed, auto_reset, env_id_offset, config,
+            track_episodes=int(bool(monitor)), **overrides)
+        self.monitor = bool(self.cfg.track_episodes)
         self.num_envs = int(self.cfg.num_envs)
         self.intruder_size = int(self.cfg.num_intruders)
         self.obs_dim = capi.obs_dim(self.cfg)
@@ -225,7 +237,12 @@ class BatchedSingleAircraftEnv:
         if self._pending is None:
             raise RuntimeError("not running an async step")
         self._pending = None
-        return self._obs, self._rew, self._done.view(self._torch.bool), LazyInfos(self._info)   # 0/1 bytes: zero-copy view
+        eps = None
+        if self.monitor:
+            def eps():
+                ret, ln = self.episode_stats()
+                return self._done.cpu().numpy(), ret.cpu().numpy(), ln.cpu().numpy()
+        return self._obs, self._rew, self._done.view(self._torch.bool), LazyInfos(self._info, episodes=eps)   # 0/1 bytes: zero-copy view
 
     def step(self, actions):
         self.step_async(actions)
@@ -261,6 +278,14 @@ class BatchedSingleAircraftEnv:
             out = torch.empty(shape, dtype=torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32, device=self.device)
         capi.check(self._lib.uam_policy(self._h, {"random": 0, "goal": 1}[kind], int(seed), out.data_ptr(), self._stream()))
         return out
+
+    def episode_stats(self):
+        """(return float64[B], length int32[B]) of each env's most recently finished episode (monitor=True)."""
+        torch = self._torch
+        ret = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
+        ln = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        capi.check(self._lib.uam_episode_stats(self._h, ret.data_ptr(), ln.data_ptr(), self._stream()))
+        return ret, ln
 
     @property
     def no_conflict(self):

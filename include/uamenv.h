@@ -106,7 +106,7 @@ typedef struct uam_config {
     int32_t  auto_reset;       /* 1: VecEnv semantics, obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
     int32_t  sparse_reward;    /* Config.sparse_reward */
     int32_t  random_own_start; /* 1: SingleAircraftRandomEnv.py:70-74 (ownship start drawn like an intruder) */
-    int32_t  reserved0;
+    int32_t  track_episodes;   /* 1: Monitor-style per-env episode return/length accumulators (bench/monitor.py:51-75) */
     uint64_t seed;             /* Philox key / default MT19937 seed base (env e gets seed + env_id_offset + e) */
     int64_t  env_id_offset;    /* global index of local env 0 when the batch is sharded across GPUs */
 
@@ -186,6 +186,12 @@ int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_o
 
 /* Write the current observation of every env without stepping. */
 int uam_observe(uam_env* env, float* obs_out, void* stream);
+
+/* Monitor-style episode statistics (needs uam_config.track_episodes = 1): for every env, the return
+ * (sum of rewards, float64) and length of the episode that ended MOST RECENTLY — valid for env e right
+ * after a step whose done_out[e] is 1 (baselines/bench/monitor.py:58-75 puts them in info['episode']).
+ * ret_out double[B], len_out int32[B], device. */
+int uam_episode_stats(uam_env* env, double* ret_out_dev, int32_t* len_out_dev, void* stream);
 
 /* Copy env.no_conflict (int32[B]) to a device buffer. */
 int uam_counters(uam_env* env, int32_t* no_conflict_out_dev, void* stream);

@@ -27,7 +27,7 @@ class UamConfig(C.Structure):
         ("struct_size", C.c_uint32), ("num_envs", C.c_int32), ("num_intruders", C.c_int32),
         ("obs_mode", C.c_int32), ("action_mode", C.c_int32), ("dynamics", C.c_int32),
         ("rng_mode", C.c_int32), ("precision", C.c_int32), ("auto_reset", C.c_int32),
-        ("sparse_reward", C.c_int32), ("random_own_start", C.c_int32), ("reserved0", C.c_int32),
+        ("sparse_reward", C.c_int32), ("random_own_start", C.c_int32), ("track_episodes", C.c_int32),
         ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
         ("window_width", C.c_double), ("window_height", C.c_double),
         ("minimum_separation", C.c_double), ("nmac_dist", C.c_double),
@@ -141,6 +141,7 @@ def lib():
         L.orc_observe.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_state.argtypes = [C.c_void_p, C.POINTER(UamStateView)]
         L.orc_set_state.argtypes = [C.c_void_p, C.POINTER(UamStateView)]
+        L.orc_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_spawn_count.restype = C.c_int64
         L.orc_spawn_count.argtypes = [C.c_void_p]
         L.orc_redraw_count.restype = C.c_int64
@@ -244,6 +245,11 @@ class OracleBatch:
         st = {k: (a if k == "step_index" else np.ascontiguousarray(a)) for k, a in st.items()}
         v = make_view(st, self.B, self.N)
         lib().orc_set_state(self._h, C.byref(v))
+
+    def episode_stats(self):
+        ret, ln = np.zeros(self.B), np.zeros(self.B, dtype=np.int32)
+        lib().orc_episode_stats(self._h, ret.ctypes.data, ln.ctypes.data)
+        return ret, ln
 
     @property
     def spawn_count(self):

@@ -138,6 +138,8 @@ typedef struct {
     uint32_t reset_count;           /* episodes started so far: Philox counter of the reset draws */
     mt_state* mt;                   /* own stream, or the shared one */
     int64_t spawns, redraws;
+    double ep_ret, ep_last_ret;     /* Monitor accumulators, baselines/bench/monitor.py:58-75 */
+    int32_t ep_len, ep_last_len;
 } env_t;
 
 struct orc_batch {
@@ -520,6 +522,11 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
     double r; int d, inf;
     terminal_reward(c, &r, &d, &inf);
     if (g->dynamics == UAM_DYN_RANDINTRUDER) update_headings(c);
+    if (g->track_episodes) {
+        c->e->ep_ret += (double)(float)r;   /* the product accumulates its float32 rewards */
+        c->e->ep_len += 1;
+        if (d) { c->e->ep_last_ret = c->e->ep_ret; c->e->ep_last_len = c->e->ep_len; c->e->ep_ret = 0.0; c->e->ep_len = 0; }
+    }
     if (d && g->auto_reset) env_reset(c);
     if (obs) env_obs(b, c->e, obs);
     reward[eidx] = r;
@@ -584,6 +591,7 @@ void orc_reset(orc_batch* b, const uint8_t* mask, double* obs_out)
         if (mask && !mask[e]) continue;
         ctx_t c = { b, &b->env[e], (uint32_t)((uint64_t)b->cfg.env_id_offset + (uint64_t)e) };
         env_reset(&c);
+        b->env[e].ep_ret = 0.0; b->env[e].ep_len = 0;
         if (obs_out) env_obs(b, &b->env[e], obs_out + (size_t)e * b->D);
     }
 }
@@ -604,6 +612,11 @@ void orc_step(orc_batch* b, const void* actions, double* obs_out, double* reward
 void orc_observe(orc_batch* b, double* obs_out)
 {
     for (int e = 0; e < b->B; e++) env_obs(b, &b->env[e], obs_out + (size_t)e * b->D);
+}
+
+void orc_episode_stats(const orc_batch* b, double* ret_out, int32_t* len_out)
+{
+    for (int e = 0; e < b->B; e++) { ret_out[e] = b->env[e].ep_last_ret; len_out[e] = b->env[e].ep_last_len; }
 }
 
 int64_t orc_spawn_count(const orc_batch* b)

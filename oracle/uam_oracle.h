@@ -44,6 +44,7 @@ void orc_step(orc_batch* b, const void* actions, double* obs_out, double* reward
 void orc_observe(orc_batch* b, double* obs_out);
 void orc_get_state(orc_batch* b, uam_state_view* v);
 void orc_set_state(orc_batch* b, const uam_state_view* v);
+void orc_episode_stats(const orc_batch* b, double* ret_out, int32_t* len_out);
 int64_t orc_spawn_count(const orc_batch* b);  /* intruder (re)spawns so far */
 int64_t orc_redraw_count(const orc_batch* b); /* rejection redraws so far */
 

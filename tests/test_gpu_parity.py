@@ -330,3 +330,41 @@ def test_seed_array_and_reseed(uamenv, oracle):
     obs = env.reset().cpu().numpy()
     assert np.abs(obs[1] - fx["obs0"]).max() <= 1e-5
     env.close()
+
+
+def test_monitor_episode_stats_match_oracle(uamenv, oracle):
+    """Monitor-style accumulators (baselines/bench/monitor.py:58-75): return and length of the episode that
+    just ended, emitted on the done step, against the oracle's; and the lazily built info['episode']."""
+    B, N, T = 256, 8, 400
+    env = uamenv.BatchedSingleAircraftEnv(B, N, seed=77, monitor=True)
+    orc = oracle.OracleBatch(pu.oracle_cfg_from(oracle, env.cfg), oracle.MATH_PORTABLE)
+    env.reset()
+    orc.reset()
+    ost = orc.get_state()
+    finished = 0
+    acc_r, acc_l = np.zeros(B), np.zeros(B, dtype=np.int64)
+    for t in range(T):
+        acts = pu.goal_seek_actions(ost, env.cfg.d_heading, 0)
+        obs, rew, done, infos = env.step(acts)
+        oo = orc.step(acts)
+        ost = orc.get_state()
+        d = done.cpu().numpy()
+        acc_r += rew.cpu().numpy().astype(np.float64)
+        acc_l += 1
+        if d.any():
+            gr, gl = env.episode_stats()
+            gr, gl = gr.cpu().numpy(), gl.cpu().numpy()
+            orr, ol = orc.episode_stats()
+            assert np.array_equal(gl[d], ol[d]) and np.array_equal(gr[d], orr[d])       # same float32 rewards summed in order
+            assert np.array_equal(gl[d], acc_l[d]) and np.allclose(gr[d], acc_r[d], rtol=0, atol=1e-9)
+            i = int(np.nonzero(d)[0][0])
+            assert infos[i]["episode"] == {"r": round(float(gr[i]), 6), "l": int(gl[i])} and "episode" not in infos[int(np.nonzero(~d)[0][0])]
+            finished += int(d.sum())
+            acc_r[d] = 0
+            acc_l[d] = 0
+    assert finished > 50
+    plain = uamenv.BatchedSingleAircraftEnv(4, 4)
+    with pytest.raises(uamenv.UamError):
+        plain.episode_stats()
+    plain.close()
+    env.close()
