@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
  * separate launch (5.5 us of pure latency at B=65536); only worth it where the fp64 phase fits the
  * sweep's register budget (the lean float32/Philox configuration). */
 template <bool POS64, int RNG, bool RI, bool SH, bool ROS, bool FUSED>
-__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p, const UamCold cv)
+__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     typedef typename PosT<POS64>::type P;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
@@ -777,7 +777,8 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p, const UamCol
         if (!does_own) quad_load<POS64, SH>(p, base, quad_ok, q);
         if (does_own) {
             const int e = blockIdx.x * p.E + tid;
-            if (e < p.B) own_compute<RNG>(p, cv, e, lds_share + 3 * tid);
+            /* cold configuration through the pointer: its scalar loads (and SGPRs) stay inside this branch */
+            if (e < p.B) own_compute<RNG>(p, *p.c, e, lds_share + 3 * tid);
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();

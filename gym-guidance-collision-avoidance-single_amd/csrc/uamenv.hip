@@ -383,15 +383,14 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
     const size_t lds = lds_stage(e, p);
     if constexpr (UAM_LEAN(POS64, RNG, SH)) {
         if (e->fused) {   /* ownship phase inside the sweep launch */
-            hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p,
-                               e->hcold);
+            hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p);
             return;
         }
     }
     if (e->cfg.random_own_start)
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, false>), grid, block, lds, st, p, e->hcold);
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, false>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, false>), grid, block, lds, st, p, e->hcold);
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, false>), grid, block, lds, st, p);
 }
 
 template <bool POS64, int RNG>
