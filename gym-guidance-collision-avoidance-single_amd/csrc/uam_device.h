@@ -778,7 +778,8 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
         if (does_own) {
             const int e = blockIdx.x * p.E + tid;
             /* cold configuration through the pointer: its scalar loads (and SGPRs) stay inside this branch */
-            if (e < p.B) own_compute<RNG>(p, *p.c, e, lds_share + 3 * tid);
+            const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();   /* see `pk` below */
+            if (e < p.B) own_compute<RNG>(pko, *pko.c, e, lds_share + 3 * tid);
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();
@@ -841,22 +842,26 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     const bool conf_any = (packed >> 16) != 0;
     const uint32_t new_conf = packed & 0xFFFFu;
 
+    /* rare paths (respawn, reset) read their parameters straight from the kernarg segment instead of
+     * the by-value copy: the hot path then does not have to keep (or spill) ~40 SGPRs for them */
+    const UamParams& pk = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
     Rng<RNG> rng;
-    rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
     bool vel_dirty = false;
     bool mt_used = false;
 
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
+        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN>(p, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true;
         }
     } else if (env_ok) {
+        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         for (;;) {
@@ -887,6 +892,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
+            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
 #pragma unroll
             for (int m = 0; m < 2; m++) {          /* one Philox block per intruder pair */
                 const uint32_t pair = 2u * gl + m;
@@ -960,7 +966,8 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* ---- VecEnv auto-reset: the obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail);
+        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
+        reset_env<POS64, RNG, SH, ROS>(pk, env, gl, quad_ok, rng, q, tail);
         vel_dirty = true;
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
