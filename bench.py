@@ -114,11 +114,17 @@ def main():
         tape = torch.randint(0, 3, (TAPE_LEN, B, 2), dtype=torch.int32, device=dev, generator=gen)
     else:
         tape = torch.rand((TAPE_LEN, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
-    rew_slab = torch.empty((GATHER_EVERY, B), dtype=torch.float32, device=dev)
-    done_slab = torch.empty((GATHER_EVERY, B), dtype=torch.uint8, device=dev)
-    if world > 1:
-        rew_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.float32, device=dev)
-        done_all = torch.empty((world * GATHER_EVERY, B), dtype=torch.uint8, device=dev)
+    # Chunk slabs: rewards (float32) and dones (uint8) of GATHER_EVERY steps live in ONE byte buffer so that a
+    # single collective moves both; two slabs alternate so the gather of chunk c overlaps the steps of chunk c+1.
+    KB = GATHER_EVERY * B
+
+    def make_slab():
+        raw = torch.empty((KB * 5,), dtype=torch.uint8, device=dev)
+        return raw, raw[:KB * 4].view(torch.float32).view(GATHER_EVERY, B), raw[KB * 4:].view(GATHER_EVERY, B)
+
+    slabs = [make_slab(), make_slab()]
+    pending = [None, None]
+    gathered = [torch.empty((world * KB * 5,), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
     acts = env.policy_actions("random")
 
     def run(nsteps, offset=0):
@@ -129,13 +135,21 @@ def main():
             else:
                 a = tape[i % TAPE_LEN]
             # rewards/dones land directly in row j of the chunk slab: identical per-step work at every N
-            j = i % GATHER_EVERY
+            c, j = (i // GATHER_EVERY) & 1, i % GATHER_EVERY
+            if j == 0 and pending[c] is not None:
+                pending[c].wait()            # the stream (not the host) waits until this slab's last gather is done
+                pending[c] = None
+            raw, rew_slab, done_slab = slabs[c]
             env.step_into(a, rew_slab[j], done_slab[j])
-            if world > 1:
-                if j == GATHER_EVERY - 1:
-                    # the one exchange of the path: reward/done slabs of the chunk, gathered over xGMI
-                    dist.all_gather_into_tensor(rew_all, rew_slab)
-                    dist.all_gather_into_tensor(done_all, done_slab)
+            if world > 1 and j == GATHER_EVERY - 1:
+                # the one exchange of the path: the chunk's reward/done slab, all-gathered over xGMI (RCCL)
+                pending[c] = dist.all_gather_into_tensor(gathered[c], raw, async_op=True)
+
+    def drain():
+        for c in (0, 1):
+            if pending[c] is not None:
+                pending[c].wait()
+                pending[c] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -144,10 +158,12 @@ def main():
             torch.cuda.synchronize()
 
     run(args.warmup)
+    drain()
     fence()
     env.timing_begin()
     t0 = time.perf_counter()
     run(args.steps, offset=args.warmup)
+    drain()
     kernel_ms = env.timing_end()      # hipEvents on the launch stream, averaged over the uam_step launches
     fence()
     elapsed = time.perf_counter() - t0
@@ -159,6 +175,7 @@ def main():
     # per-kernel durations: a separate pass with hipEvents around each launch (not part of `value`)
     env.kernel_timing(True)
     run(256, offset=args.warmup + args.steps)
+    drain()
     own_ms, sweep_ms, nsamp = env.kernel_timing_read()
     env.kernel_timing(False)
 
@@ -188,7 +205,8 @@ def main():
                        else "%s variant, batch=%d x %d intruders per GPU" % (args.variant, B, N),
                        "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": args.rng,
                        "variant": args.variant, "positions": "float32" if args.precision == "f32" else "float64 (exact promotion)", "obs": "float32[B,%d] written every step" % env.obs_dim,
-                       "exchange": "none" if world == 1 else "all_gather(reward,done) every %d steps" % GATHER_EVERY},
+                       "exchange": "none" if world == 1 else "one async all_gather of the [%d, B] reward+done slab per chunk, "
+                                   "double-buffered (overlaps the next chunk)" % GATHER_EVERY},
             "pair_steps_per_sec": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
