@@ -590,7 +590,11 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, 
         const int chunks = nrows * (p.D >> 2);
         float4* gdst = (float4*)(p.obs + (size_t)env_first * p.D);
         const float4* src = (const float4*)stage;
-        for (int c = lane; c < chunks; c += 64) gdst[c] = src[c];
+        /* non-temporal: the observation is written once and never read back by the env, so it must not
+         * evict the SoA state (re-read next step) from L2 / Infinity Cache: -8 % at 65536 envs, -16 % at 1 M */
+        typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
+        for (int c = lane; c < chunks; c += 64)
+            __builtin_nontemporal_store(((const uam_f32x4*)src)[c], &((uam_f32x4*)gdst)[c]);
     } else if (env_ok) {
         float* row = p.obs + (size_t)(env_first + g_in_wave) * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, false, min(4, p.N - 4 * gl), q);
