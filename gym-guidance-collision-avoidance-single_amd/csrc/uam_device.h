@@ -752,8 +752,8 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
 /* FUSED: the ownship phase runs inside this launch — the first E threads of the block compute the
  * block's E envs (one thread per env) while the other waves already have their quad loads in flight,
  * hand the 48-byte records over through LDS, and one block barrier later everyone sweeps.  Saves the
- * separate launch (5.5 us of pure latency at B=65536); only worth it where the fp64 phase fits the
- * sweep's register budget (the lean float32/Philox configuration). */
+ * separate launch (5.5 us of pure latency at B=65536).  Used by every Philox configuration; the threads
+ * that run the ownship phase fetch their quad after it, so the phase never adds register pressure. */
 template <bool POS64, int RNG, bool RI, bool SH, bool ROS, bool FUSED>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {

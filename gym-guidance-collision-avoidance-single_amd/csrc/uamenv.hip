@@ -256,7 +256,9 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->E = T / L;
     e->D = uam_obs_dim(cfg);
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
-    e->fused = cfg->precision == UAM_POS_F32 && cfg->rng_mode == UAM_RNG_PHILOX && !e->hold_sh && !cfg->random_own_start;
+    /* Philox configurations run the ownship phase inside the sweep launch (one launch per step); the
+     * MT19937 stream and the random-ownship-start variant keep the separate ownship kernel */
+    e->fused = cfg->rng_mode == UAM_RNG_PHILOX && !cfg->random_own_start;
     if (const char* fz = getenv("UAMENV_FUSED")) e->fused = e->fused && atoi(fz) != 0;   /* development override */
 
     const size_t BI = (size_t)B * e->Np;
@@ -381,7 +383,7 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
 {
     dim3 grid(grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
-    if constexpr (UAM_LEAN(POS64, RNG, SH)) {
+    if constexpr (RNG == UAM_RNG_PHILOX) {
         if (e->fused) {   /* ownship phase inside the sweep launch */
             hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p);
             return;
