@@ -82,9 +82,9 @@ __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepai
     uint32_t w[4];
     mcts_philox(r, framepair, purpose, idx, w);
     const double u1 = uam_u53_open0(w[0], w[1]), u2 = uam_u53(w[2], w[3]);
-    const double rr = __builtin_sqrt(-2.0 * uam_log(u1));
+    const double rr = __builtin_sqrt(-2.0 * uam_log_k(u1));
     double sn, cs;
-    uam_sincos(UAM_TWO_PI * u2, &sn, &cs);
+    uam_sincos_k(UAM_TWO_PI * u2, &sn, &cs);
     z0 = rr * cs;
     z1 = rr * sn;
 }
@@ -126,7 +126,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
     }
     /* ---- every frame's velocity at once, :81-82 */
     double sn, cs;
-    uam_sincos(my_hd, &sn, &cs);
+    uam_sincos_k(my_hd, &sn, &cs);
     const double my_vx = my_sp * cs, my_vy = my_sp * sn;
     /* ---- positions in frame order, :83-86 */
     double ox = s.ox, oy = s.oy, my_ox = 0.0, my_oy = 0.0;
@@ -168,7 +168,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                     const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
                     s.hd[k] += deg * UAM_DEG2RAD;
                     double isn, ics;
-                    uam_sincos(s.hd[k], &isn, &ics);
+                    uam_sincos_k(s.hd[k], &isn, &ics);
                     s.vx[k] = sp[k] * ics;
                     s.vy[k] = sp[k] * isn;
                 }
@@ -314,7 +314,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 break;
             }
             /* best_child(c_param), common.py:47-52: lanes 0..8 weigh one child each, first maximum wins */
-            const double logn = uam_log(t.n[v]);
+            const double logn = uam_log_k(t.n[v]);
             double w = -1.0e300;
             if (lane < 9) {
                 const int c = t.child[v][lane];
@@ -354,7 +354,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
     {
         double w = -1.0e300;
         const int nc = t.nchild[0];
-        const double logn = uam_log(t.n[0]);
+        const double logn = uam_log_k(t.n[0]);
         if (lane < nc) {
             const int c = t.child[0][lane];
             const double cn = t.n[c];
