@@ -8,13 +8,15 @@ of the env interface (`envs.py`).
 from . import _capi
 from ._capi import UamError, build, default_config
 from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2Env, SingleAircraftEnv,
-                   SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv, make_config)
+                   SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv,
+                   SingleAircraftDiscrete9HEREnv, make_config)
 from . import spaces
 from .sharded import ShardedSingleAircraftEnv, shard_bounds
 from .mcts import BatchedMCTS, mcts_config
 
 __all__ = [
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
-    "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv", "make_config",
+    "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv",
+    "SingleAircraftDiscrete9HEREnv", "make_config",
     "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds", "BatchedMCTS", "mcts_config",
 ]

@@ -13,12 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("UAMENV_LIB") or os.path.join(CSRC, "libuamenv_hip.so")   # UAMENV_LIB: development override
 
-OBS_NORM4, OBS_RAW4, OBS_RAW6 = 0, 1, 2
+OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
 ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1 = 0, 1, 2
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1
-INFO_CODES = ("", "c", "g", "n")   # SingleAircraftEnv.py:168,172,180,183
+INFO_CODES = ("", "c", "g", "n", "w")   # SingleAircraftEnv.py:168,172,180,183
 
 
 class UamError(RuntimeError):
@@ -45,6 +45,7 @@ class UamConfig(C.Structure):
         ("step_penalty", C.c_double), ("goal_reward", C.c_double), ("dense_reward_div", C.c_double),
         ("own_x0", C.c_double), ("own_y0", C.c_double), ("own_speed0", C.c_double), ("own_heading0", C.c_double),
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
+        ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
     ]
 
 

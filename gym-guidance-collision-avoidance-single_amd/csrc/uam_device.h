@@ -89,13 +89,14 @@ struct UamCold {
     double inv_2vmax, inv_vrange, inv_W, inv_H;   /* reciprocals for the float32 obs tail (tolerance, not parity) */
     double own_vx0, own_vy0;      /* float32(own_speed0 * cos/sin(own_heading0)), SingleAircraftEnv.py:275-277 */
     double sep2, nmac2, init2;    /* float64 squared-distance thresholds: min{v : sqrt(v) >= thr} */
+    double wall_pen, inv_diag;    /* HER env family: wall penalty, 1/Config.diagonal */
 };
 
 struct UamParams {
     UamDev s;
     const UamCold* c;
     int B, N, Np, Q, L, lshift, E, D;
-    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep;
+    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep, wall_term, knn;
     uint32_t seed_lo, seed_hi, gid0;
     uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
     float W32, H32, vmax32, psig32;
@@ -120,7 +121,7 @@ struct UamParams {
 struct OwnShare {
     float own_x, own_y;
     float rew_tail;      /* reward if neither NMAC nor conflict: goal reward or dense/sparse step reward */
-    uint32_t goal_hit;
+    uint32_t tail_code;  /* 0 none, 1 goal reached, 2 ownship left the map */
     float tail[8];       /* ownship(6) + goal(2) part of the observation */
 };
 
@@ -715,7 +716,10 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     const double dx = (double)ox - gx, dy = (double)oy - gy;
     const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
     const bool hit = dg < c.goal_r;
-    const float rew = hit ? (float)c.goal_rew : (p.sparse_reward ? (float)c.step_pen : (float)(-dg / c.dense_div));
+    /* SingleAircraftDiscrete9HEREnv.py:217-221: leaving the map ends the episode (checked before the goal) */
+    const bool wall = p.wall_term && !(ox >= 0.f && oy >= 0.f && ox <= p.W32 && oy <= p.H32);
+    const float rew = wall ? (float)c.wall_pen
+                           : hit ? (float)c.goal_rew : (p.sparse_reward ? (float)c.step_pen : (float)(-dg / c.dense_div));
     float t[8];
     if (p.obs_mode == UAM_OBS_NORM4) {
         t[0] = ox * p.inv_W32;
@@ -733,7 +737,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     own_x[e] = ox; own_y[e] = oy;
     own_h[e] = hd; own_s[e] = sp;
     p.s.own_vx[e] = vx; p.s.own_vy[e] = vy;
-    sh[0] = make_float4(ox, oy, rew, __uint_as_float(hit ? 1u : 0u));
+    sh[0] = make_float4(ox, oy, rew, __uint_as_float(wall ? 2u : (hit ? 1u : 0u)));   /* tail code: 0 none, 1 goal, 2 wall */
     sh[1] = make_float4(t[0], t[1], t[2], t[3]);
     sh[2] = make_float4(t[4], t[5], t[6], t[7]);
 }
@@ -884,13 +888,13 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     }
 
     /* ---- reward / done / info, :167-185 */
-    const bool goal_hit = __float_as_uint(s0.w) != 0u;
+    const uint32_t tail_code = __float_as_uint(s0.w);
     bool done;
     uint32_t info;
     float reward;
     if (nmac_any) { reward = p.nmac_pen32; done = true; info = UAM_INFO_NMAC; }
     else if (conf_any) { reward = p.conf_pen32; done = false; info = UAM_INFO_CONFLICT; }
-    else if (goal_hit) { reward = s0.z; done = true; info = UAM_INFO_GOAL; }
+    else if (tail_code) { reward = s0.z; done = true; info = tail_code == 2u ? UAM_INFO_WALL : UAM_INFO_GOAL; }
     else { reward = s0.z; done = false; info = UAM_INFO_NONE; }
 
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
@@ -1050,6 +1054,82 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_observe_kernel(const UamPar
                  p.s.goal_x[env], p.s.goal_y[env], tail);
     float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
     obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+}
+
+/* UAM_OBS_KNN5: SingleAircraftDiscrete9HEREnv._get_ob (Discrete9HEREnv.py:105-165) from the CURRENT state,
+ * one lane group per env: every lane computes the distances of its quad, then `knn` rounds of an in-group
+ * (distance, index) min-reduction pick the nearest remaining intruder (ascending distance, ties to the
+ * lower index — np.argpartition + argsort); the owner lane writes that neighbour's 5 values.  Runs as its
+ * own launch after the sweep (which is then told to skip the obs): the rows are 4 + 5 knn + 4 floats. */
+template <bool POS64>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_knn_obs_kernel(const UamParams p)
+{
+    const int tid = threadIdx.x;
+    const int L = p.L;
+    const int g = tid >> p.lshift, gl = tid & (L - 1);
+    const int env = blockIdx.x * p.E + g;
+    if (env >= p.B) return;                       /* whole lane group: shuffles stay inside the group */
+    const bool quad_ok = gl < p.Q;
+    const size_t base = (size_t)env * p.Np + 4u * gl;
+    Quad<POS64, false> q;
+    quad_load<POS64, false>(p, base, quad_ok, q);
+    const float ox = p.s.own_x[env], oy = p.s.own_y[env];
+    double d[4];
+    uint32_t avail = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
+        if (POS64 && prom) {
+            const double dx = (double)ox - (double)q.x[j], dy = (double)oy - (double)q.y[j];
+            d[j] = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
+        } else {
+            const float dx = ox - (float)q.x[j], dy = oy - (float)q.y[j];
+            d[j] = (double)__builtin_sqrtf(dx * dx + dy * dy);
+        }
+        if (quad_ok && 4u * gl + j < (uint32_t)p.N) avail |= 1u << j;
+    }
+    float* row = p.obs + (size_t)env * p.D;
+    for (int r = 0; r < p.knn; r++) {
+        double bd = 1.0e300;
+        int bj = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (((avail >> j) & 1u) && d[j] < bd) { bd = d[j]; bj = j; }
+        uint32_t bi = bj >= 0 ? 4u * gl + (uint32_t)bj : 0xFFFFu;
+        double gd = bd;
+        uint32_t gi = bi;
+        for (int o = L >> 1; o > 0; o >>= 1) {
+            const double d2 = __shfl_xor(gd, o);
+            const uint32_t i2 = (uint32_t)__shfl_xor((int)gi, o);
+            if (d2 < gd || (d2 == gd && i2 < gi)) { gd = d2; gi = i2; }
+        }
+        if (gi == bi && bj >= 0) {                 /* this lane owns the r-th nearest intruder */
+            avail &= ~(1u << bj);
+            float* dst = row + 4 + 5 * r;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j == bj) {
+                    const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
+                    dst[0] = prom ? (float)((double)q.x[j] * p.c->inv_W) : (float)q.x[j] * p.inv_W32;
+                    dst[1] = prom ? (float)((double)q.y[j] * p.c->inv_H) : (float)q.y[j] * p.inv_H32;
+                    dst[2] = (q.vx[j] + p.vmax32) * p.inv_vden32;
+                    dst[3] = (q.vy[j] + p.vmax32) * p.inv_vden32;
+                    dst[4] = (float)(bd * p.c->inv_diag);
+                }
+        }
+    }
+    if (gl == 0) {
+        const double ovx = p.s.own_vx[env], ovy = p.s.own_vy[env];
+        row[0] = ox * p.inv_W32;
+        row[1] = oy * p.inv_H32;
+        row[2] = (float)((ovx + p.c->max_speed) * p.c->inv_2vmax);
+        row[3] = (float)((ovy + p.c->max_speed) * p.c->inv_2vmax);
+        float* tl = row + 4 + 5 * p.knn;
+        tl[0] = ox * p.inv_W32;                                  /* achieved_goal */
+        tl[1] = oy * p.inv_H32;
+        tl[2] = (float)(p.s.goal_x[env] * p.c->inv_W);           /* desired_goal */
+        tl[3] = (float)(p.s.goal_y[env] * p.c->inv_H);
+    }
 }
 
 /* ownship noise drawn ahead for K consecutive steps (Philox): out[k*B + e] = (zh, zs) of step base+k.

@@ -61,6 +61,7 @@ extern "C" const char* uam_version(void) { return "uamenv-hip 0.1 (gfx950, abi 1
 
 extern "C" int32_t uam_obs_dim(const uam_config* cfg)
 {
+    if (cfg->obs_mode == UAM_OBS_KNN5) return 4 + 5 * cfg->knn + 4;
     return (cfg->obs_mode == UAM_OBS_RAW6 ? 6 : 4) * cfg->num_intruders + 8;
 }
 
@@ -89,6 +90,7 @@ extern "C" int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->goal_reward = 10 / 10.0; c->dense_reward_div = 1200;
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = pi / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
+    c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
     return UAM_OK;
 }
 
@@ -102,7 +104,13 @@ static int validate(const uam_config* c)
         return fail(UAM_EINVAL, "num_intruders must be in 1..256 (got %d)", c->num_intruders);
     if ((int64_t)c->num_envs * ((c->num_intruders + 3) & ~3) > (int64_t)1 << 31)
         return fail(UAM_EINVAL, "num_envs*num_intruders too large for one handle");
-    if (c->obs_mode < 0 || c->obs_mode > UAM_OBS_RAW6) return fail(UAM_EINVAL, "bad obs_mode %d", c->obs_mode);
+    if (c->obs_mode < 0 || c->obs_mode > UAM_OBS_KNN5) return fail(UAM_EINVAL, "bad obs_mode %d", c->obs_mode);
+    if (c->obs_mode == UAM_OBS_KNN5) {
+        if (c->knn < 1 || c->knn >= c->num_intruders)
+            return fail(UAM_EINVAL, "UAM_OBS_KNN5 needs 1 <= knn < num_intruders (np.argpartition(dist, knn)); got knn=%d, N=%d", c->knn, c->num_intruders);
+        if (!(c->diagonal > 0)) return fail(UAM_EINVAL, "diagonal must be positive");
+        if (c->dynamics == UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "UAM_OBS_KNN5 is not defined for the RandIntruder dynamics");
+    }
     if (c->action_mode < 0 || c->action_mode > UAM_ACT_CONTINUOUS1) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
     if (c->dynamics < 0 || c->dynamics > UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "bad dynamics %d", c->dynamics);
     if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
@@ -178,6 +186,7 @@ static void fill_cold(const uam_config& c, UamCold* k)
     k->own_vx0 = (double)(float)(c.own_speed0 * cs); k->own_vy0 = (double)(float)(c.own_speed0 * sn);
     k->sep2 = sq_threshold_f64(c.minimum_separation); k->nmac2 = sq_threshold_f64(c.nmac_dist);
     k->init2 = sq_threshold_f64(c.initial_min_dist);
+    k->wall_pen = c.wall_penalty; k->inv_diag = c.diagonal > 0 ? 1.0 / c.diagonal : 0.0;
 }
 
 static void fill_params(const uam_env* e, UamParams* p)
@@ -191,6 +200,8 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->obs_mode = c.obs_mode; p->action_mode = c.action_mode; p->auto_reset = c.auto_reset;
     p->sparse_reward = c.sparse_reward;
     p->track_ep = c.track_episodes ? 1 : 0;
+    p->wall_term = c.wall_terminates ? 1 : 0;
+    p->knn = c.knn;
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
@@ -443,6 +454,14 @@ static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
     else { if (sh) launch_reset_ros<false, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_PHILOX, false>(e, p, st); }
 }
 
+/* UAM_OBS_KNN5 rows are produced by their own launch from the committed state */
+static void launch_knn_obs(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    if (e->cfg.precision == UAM_POS_EXACT) hipLaunchKernelGGL((uam_knn_obs_kernel<true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((uam_knn_obs_kernel<false>), grid, block, 0, st, p);
+}
+
 static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)
 {
     if (obs && ((uintptr_t)obs & 3u)) return fail(UAM_EINVAL, "obs_out must be 4-byte aligned");
@@ -459,8 +478,10 @@ extern "C" int uam_reset(uam_env* e, const uint8_t* mask_dev, float* obs_out, vo
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.mask = mask_dev;
-    p.obs = obs_out;
+    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
+    p.obs = knn ? nullptr : obs_out;
     launch_reset(e, p, (hipStream_t)stream);
+    if (knn && obs_out) { p.obs = obs_out; launch_knn_obs(e, p, (hipStream_t)stream); }
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
@@ -486,7 +507,10 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
         }
         p.noise = e->noise + (size_t)(e->step_index - e->noise_base) * e->cfg.num_envs;
     }
+    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
+    if (knn) p.obs = nullptr;
     launch_step(e, p, st);
+    if (knn && obs_out) { p.obs = obs_out; launch_knn_obs(e, p, st); }
     HIP_TRY(hipGetLastError());
     e->step_index++;
     if (e->timing) e->timed_launches++;
@@ -541,6 +565,11 @@ extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.obs = obs_out;
+    if (e->cfg.obs_mode == UAM_OBS_KNN5) {
+        launch_knn_obs(e, p, (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+        return UAM_OK;
+    }
     dim3 grid(grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
     const bool x = e->cfg.precision == UAM_POS_EXACT;
@@ -593,7 +622,7 @@ extern "C" int64_t uam_step_bytes(const uam_env* e)
 {
     if (!e) return 0;
     const int64_t posb = e->cfg.precision == UAM_POS_EXACT ? 8 : 4;
-    const int64_t obs_w = e->cfg.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
+    const int64_t obs_w = e->cfg.obs_mode == UAM_OBS_RAW6 ? 6 : (e->cfg.obs_mode == UAM_OBS_KNN5 ? 2 : 4);   /* KNN5: x,y re-read */
     /* per intruder: x,y read + write, vx,vy read, obs write (+ speed,heading read when held);
      * per env: SURVEY §8d's 150 B (ownship, goal, flags, counters, action, obs tail, reward/done/info) */
     const int64_t per_int = 4 * posb + 8 + 4 * obs_w + (e->hold_sh ? 16 : 0);

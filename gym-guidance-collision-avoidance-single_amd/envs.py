@@ -64,6 +64,7 @@ _VARIANTS = {
     "mcts": (capi.OBS_RAW4, capi.ACT_PAIR, capi.DYN_STRAIGHT, 0),                # Simulators/SingleAircraftMCTSEnv.py
     "randintruder": (capi.OBS_RAW6, capi.ACT_PAIR, capi.DYN_RANDINTRUDER, 0),    # ...MCTSRandIntruderEnv.py
     "random_start": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),  # Simulators/SingleAircraftRandomEnv.py
+    "her9": (capi.OBS_KNN5, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),           # ...Discrete9HEREnv.py (k-nearest obs)
 }
 _RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
 _PREC = {"f32": capi.POS_F32, "exact": capi.POS_EXACT}
@@ -87,7 +88,9 @@ def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox",
         d_heading=config.d_heading, heading_sigma=config.heading_sigma,
         nmac_penalty=config.NMAC_penalty, conflict_penalty=config.conflict_penalty,
         step_penalty=config.step_penalty, goal_reward=config.goal_reward,
-        own_speed0=config.min_speed)
+        own_speed0=config.min_speed, wall_penalty=config.wall_penalty, diagonal=config.diagonal, knn=int(config.n),
+        # the HER env ends the episode when the ownship leaves the map, but only under sparse_reward (:217-221)
+        wall_terminates=int(variant == "her9" and bool(config.sparse_reward)))
     for k, v in overrides.items():
         if not hasattr(cfg, k):
             raise AttributeError("uam_config has no field %r" % k)
@@ -152,8 +155,10 @@ class BatchedSingleAircraftEnv:
         self.num_envs = int(self.cfg.num_envs)
         self.intruder_size = int(self.cfg.num_intruders)
         self.obs_dim = capi.obs_dim(self.cfg)
-        # observation_space advertises 4N+8 even for the 6-wide RandIntruder obs (RandIntruderEnv.py:51-52)
-        self.observation_space = spaces.Box(low=-1000, high=1000, shape=(self.intruder_size * 4 + 8,), dtype=np.float32)
+        # observation_space advertises 4N+8 even for the 6-wide RandIntruder obs (RandIntruderEnv.py:51-52);
+        # the HER env advertises len(observation) + 2 (Discrete9HEREnv.py:42)
+        nobs = (4 + 5 * int(self.cfg.knn) + 2) if self.cfg.obs_mode == capi.OBS_KNN5 else self.intruder_size * 4 + 8
+        self.observation_space = spaces.Box(low=-1000, high=1000, shape=(nobs,), dtype=np.float32)
         if self.cfg.action_mode == capi.ACT_CONTINUOUS1:
             self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float64)
         else:
@@ -433,3 +438,56 @@ class SingleAircraftMCTSRandIntruderEnv(SingleAircraftMCTSEnv):
 class SingleAircraftRandomEnv(SingleAircraftEnv):
     """Simulators/SingleAircraftRandomEnv.py: ownship start drawn like an intruder."""
     _variant = "random_start"
+
+
+class SingleAircraftDiscrete9HEREnv(SingleAircraftEnv):
+    """Simulators/SingleAircraftDiscrete9HEREnv.py: gym.GoalEnv-style dict observation with the `Config.n`
+    nearest intruders (ascending distance), random ownship start, out-of-map termination under
+    sparse_reward.  Like the reference, the constructor already runs one reset() (:32)."""
+    _variant = "her9"
+
+    def __init__(self, num_intruders=None, seed=None, device=None, rng="mt19937", precision="exact", config=Config,
+                 **overrides):
+        super().__init__(num_intruders, seed, device, rng, precision, config, **overrides)
+        self._config = config
+        self.goal_radius = config.goal_radius
+        self.minimum_separation = config.minimum_separation
+        self.NMAC_dist = config.NMAC_dist
+        self.reset()
+
+    def seed(self, seed=None):
+        out = super().seed(seed)
+        self.reset()          # np.random.seed(s); env = Env() in the reference: the constructor's reset comes first
+        return out
+
+    def _obs_np(self, t):
+        row = t[0].cpu().numpy().astype(np.float64)
+        k = 4 + 5 * int(self._vec.cfg.knn)
+        return {"observation": row[:k], "achieved_goal": row[k:k + 2], "desired_goal": row[k + 2:k + 4]}
+
+    def compute_reward(self, achieved_goal, desired_goal, info):
+        """Discrete9HEREnv.py:229-243 (without its in-place un-normalisation of the arguments)."""
+        c = self._config
+        a = np.asarray(achieved_goal, dtype=np.float64) * np.array([c.window_width, c.window_height])
+        g = np.asarray(desired_goal, dtype=np.float64) * np.array([c.window_width, c.window_height])
+        d = np.linalg.norm(a - g, axis=-1)
+        if d < self.goal_radius:
+            return c.goal_reward
+        return c.step_penalty if c.sparse_reward else -d / 1200
+
+    def compute_input_reward(self, new_inputs):
+        """Discrete9HEREnv.py:245-276."""
+        c = self._config
+        x = np.asarray(new_inputs, dtype=np.float64)
+        ownx, owny = x[0] * c.window_width, x[1] * c.window_height
+        gx, gy = x[-2] * c.window_width, x[-1] * c.window_height
+        dist_goal = math.sqrt((ownx - gx) ** 2 + (owny - gy) ** 2)
+        if c.intruder_size != 0:
+            for idx in range(c.n):
+                ix, iy = x[idx * 4 + 4] * c.window_width, x[idx * 4 + 5] * c.window_height
+                di = math.sqrt((ownx - ix) ** 2 + (owny - iy) ** 2)
+                if di < self.minimum_separation:
+                    return c.NMAC_penalty if di < self.NMAC_dist else c.conflict_penalty
+        if dist_goal < self.goal_radius:
+            return c.goal_reward
+        return c.step_penalty if c.sparse_reward else -dist_goal / 1200

@@ -54,7 +54,10 @@ extern "C" {
 enum {
     UAM_OBS_NORM4 = 0,  /* SingleAircraftEnv.py:98-124: [x/W, y/H, nvx, nvy]*N + own(6) + goal(2), D = 4N+8 */
     UAM_OBS_RAW4  = 1,  /* SingleAircraftMCTSEnv.py:98-124: raw [x, y, vx, vy]*N + own(6) + goal(2), D = 4N+8 */
-    UAM_OBS_RAW6  = 2   /* SingleAircraftMCTSRandIntruderEnv.py:124-152: raw [x,y,vx,vy,speed,heading]*N + own(6) + goal(2), D = 6N+8 */
+    UAM_OBS_RAW6  = 2,  /* SingleAircraftMCTSRandIntruderEnv.py:124-152: raw [x,y,vx,vy,speed,heading]*N + own(6) + goal(2), D = 6N+8 */
+    UAM_OBS_KNN5  = 3   /* SingleAircraftDiscrete9HEREnv.py:105-165 (GoalEnv dict, flattened): own [x/W, y/H, nvx, nvy] +
+                           [x/W, y/H, nvx, nvy, dist/diagonal] of the `knn` nearest intruders by ascending distance +
+                           achieved_goal(2) + desired_goal(2), D = 4 + 5*knn + 4; needs N > knn */
 };
 
 /* ---- action encodings ---- */
@@ -90,7 +93,8 @@ enum {
 };
 
 /* ---- info codes written to info_out (the reference's 'result' strings) ---- */
-enum { UAM_INFO_NONE = 0 /* '' */, UAM_INFO_CONFLICT = 1 /* 'c' */, UAM_INFO_GOAL = 2 /* 'g' */, UAM_INFO_NMAC = 3 /* 'n' */ };
+enum { UAM_INFO_NONE = 0 /* '' */, UAM_INFO_CONFLICT = 1 /* 'c' */, UAM_INFO_GOAL = 2 /* 'g' */, UAM_INFO_NMAC = 3 /* 'n' */,
+       UAM_INFO_WALL = 4 /* 'w': ownship left the map, SingleAircraftDiscrete9HEREnv.py:218-221 (wall_terminates) */ };
 
 /* POD snapshot of Simulators/config.py plus the batch geometry and mode
  * switches.  Fill with uam_config_default() and then override. */
@@ -118,6 +122,12 @@ typedef struct uam_config {
     double dense_reward_div;                                              /* 1200, SingleAircraftEnv.py:185 */
     double own_x0, own_y0, own_speed0, own_heading0;                      /* SingleAircraftEnv.py:70-74 */
     double heading_change_prob, heading_change_max_deg;                   /* 0.1, 10: RandIntruderEnv.py:170-173 */
+    /* HER env family (SingleAircraftDiscrete9HEREnv.py) */
+    double wall_penalty;       /* Config.wall_penalty, config.py:39 */
+    double diagonal;           /* Config.diagonal (normalises dist_to_intruder), config.py:8 */
+    int32_t knn;               /* Config.n, nearest intruders in the UAM_OBS_KNN5 observation, config.py:55 */
+    int32_t wall_terminates;   /* 1: out-of-map ownship ends the episode with wall_penalty (the reference does this
+                                  only when sparse_reward is set, Discrete9HEREnv.py:217-221) */
 } uam_config;
 
 /* HOST-side view used by uam_get_state / uam_set_state (checkpoint, parity

@@ -12,13 +12,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
-OBS_NORM4, OBS_RAW4, OBS_RAW6 = 0, 1, 2
+OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
 ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1 = 0, 1, 2
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1
 MATH_LIBM, MATH_PORTABLE = 0, 1
-INFO_CODES = ["", "c", "g", "n"]
+INFO_CODES = ["", "c", "g", "n", "w"]
 
 
 class UamConfig(C.Structure):
@@ -39,6 +39,7 @@ class UamConfig(C.Structure):
         ("step_penalty", C.c_double), ("goal_reward", C.c_double), ("dense_reward_div", C.c_double),
         ("own_x0", C.c_double), ("own_y0", C.c_double), ("own_speed0", C.c_double), ("own_heading0", C.c_double),
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
+        ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
     ]
 
 

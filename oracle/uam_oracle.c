@@ -346,9 +346,52 @@ static void env_reset(const ctx_t* c)
 
 /* _get_ob, :98-124 (NORM4); SingleAircraftMCTSEnv.py:98-124 (RAW4);
  * SingleAircraftMCTSRandIntruderEnv.py:124-152 (RAW6).  NEP-50 arithmetic. */
+/* SingleAircraftDiscrete9HEREnv._get_ob, Discrete9HEREnv.py:105-165, flattened: observation, achieved_goal,
+ * desired_goal.  n nearest by np.argpartition + argsort of the distances (ascending; ties: lower index). */
+static void env_obs_knn(const orc_batch* b, const env_t* e, double* o)
+{
+    const uam_config* g = &b->cfg;
+    const float W32 = (float)g->window_width, H32 = (float)g->window_height;
+    const float vmax32 = (float)g->max_speed, vden32 = (float)(g->max_speed * 2);
+    int k = 0;
+    o[k++] = (double)(e->own_x / W32);
+    o[k++] = (double)(e->own_y / H32);
+    if (e->own_v_f32) {
+        o[k++] = (double)((float)((float)e->own_vx + vmax32) / vden32);
+        o[k++] = (double)((float)((float)e->own_vy + vmax32) / vden32);
+    } else {
+        o[k++] = (e->own_vx + g->max_speed) / (g->max_speed * 2);
+        o[k++] = (e->own_vy + g->max_speed) / (g->max_speed * 2);
+    }
+    unsigned char* used = (unsigned char*)calloc((size_t)b->N, 1);
+    for (int r = 0; r < g->knn; r++) {
+        int best = -1;
+        double bd = 0;
+        for (int i = 0; i < b->N; i++) {
+            if (used[i]) continue;
+            double d = dist_own_intruder(e, &e->in[i]);
+            if (best < 0 || d < bd) { best = i; bd = d; }
+        }
+        used[best] = 1;
+        const intruder_t* it = &e->in[best];
+        if (!it->promoted) { o[k++] = (double)((float)it->x / W32); o[k++] = (double)((float)it->y / H32); }
+        else { o[k++] = it->x / g->window_width; o[k++] = it->y / g->window_height; }
+        o[k++] = (double)((float)(it->vx + vmax32) / vden32);
+        o[k++] = (double)((float)(it->vy + vmax32) / vden32);
+        /* dist / Config.diagonal: float32 distance / int -> float32; float64 distance -> float64 */
+        o[k++] = it->promoted ? bd / g->diagonal : (double)((float)bd / (float)g->diagonal);
+    }
+    free(used);
+    o[k++] = (double)(e->own_x / W32);      /* achieved_goal (float32 array) */
+    o[k++] = (double)(e->own_y / H32);
+    o[k++] = e->goal_x / g->window_width;   /* desired_goal */
+    o[k++] = e->goal_y / g->window_height;
+}
+
 static void env_obs(const orc_batch* b, const env_t* e, double* o)
 {
     const uam_config* g = &b->cfg;
+    if (g->obs_mode == UAM_OBS_KNN5) { env_obs_knn(b, e, o); return; }
     const float W32 = (float)g->window_width, H32 = (float)g->window_height;
     const float vmax32 = (float)g->max_speed, vden32 = (float)(g->max_speed * 2);
     int k = 0;
@@ -461,6 +504,12 @@ static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info
         }
     }
     if (conflict) { *reward = g->conflict_penalty; *done = 0; *info = UAM_INFO_CONFLICT; return; }  /* :171-172 */
+    if (g->wall_terminates) {   /* SingleAircraftDiscrete9HEREnv.py:217-221: position_range.contains(drone.position) */
+        const float W32 = (float)g->window_width, H32 = (float)g->window_height;
+        if (!(e->own_x >= 0.f && e->own_y >= 0.f && e->own_x <= W32 && e->own_y <= H32)) {
+            *reward = g->wall_penalty; *done = 1; *info = UAM_INFO_WALL; return;
+        }
+    }
     double dg = dist_own_goal(e);
     if (dg < g->goal_radius) { *reward = g->goal_reward; *done = 1; *info = UAM_INFO_GOAL; return; } /* :179-180 */
     if (g->sparse_reward) { *reward = g->step_penalty; *done = 0; *info = UAM_INFO_NONE; return; }   /* :182-183 */
@@ -741,6 +790,7 @@ double orc_pmath_log(double x) { return uam_log(x); }
 #ifndef UAM_ORACLE_NO_CONFIG
 int32_t uam_obs_dim(const uam_config* cfg)
 {
+    if (cfg->obs_mode == UAM_OBS_KNN5) return 4 + 5 * cfg->knn + 4;
     return (cfg->obs_mode == UAM_OBS_RAW6 ? 6 : 4) * cfg->num_intruders + 8;
 }
 
@@ -763,6 +813,7 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->goal_reward = 10 / 10.0; c->dense_reward_div = 1200;
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = M_PI / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
+    c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
     return 0;
 }
 #endif

@@ -13,6 +13,10 @@ TRAJECTORY_FIXTURES = [
     "g9b_mctsenv_n8_seed11",
 ]
 
+# SingleAircraftDiscrete9HEREnv (k-nearest observation, random ownship start, optional wall termination);
+# its __init__ runs one reset() before the recorded one
+HER_FIXTURES = ["g13_her9_n8_seed41", "g13_her9_n32_seed42", "g13_her9_sparse_n8_seed43"]
+
 STATE_KEYS = ["int_x", "int_y", "int_vx", "int_vy", "int_speed", "int_heading", "int_conflict", "int_promoted",
               "own_x", "own_y", "own_heading", "own_speed", "own_vx", "own_vy", "goal_x", "goal_y", "no_conflict"]
 
@@ -32,6 +36,9 @@ def config_overrides(fx, **extra):
     for k in ("heading_sigma", "speed_sigma"):
         if "meta_" + k in fx:
             over[k] = float(fx["meta_" + k])
+    if int(fx["meta_obs_mode"]) == 3:   # HER family
+        sparse = int(fx["meta_sparse_reward"])
+        over.update(knn=int(fx["meta_knn"]), random_own_start=1, sparse_reward=sparse, wall_terminates=sparse)
     over.update(extra)
     return over
 

@@ -77,7 +77,7 @@ def run_lockstep(uamenv, oracle, B, N, T, policy="random", seed=123, check_state
     assert (d <= obs_tol * np.maximum(1.0, np.abs(oobs))).all(), "reset obs differs: %g" % d.max()
     compare_states(env.get_state(), orc.get_state(), "after reset", hold_sh=hold_sh)
     rs = np.random.RandomState(act_seed)
-    counts = np.zeros(4, dtype=np.int64)
+    counts = np.zeros(5, dtype=np.int64)
     ost = orc.get_state()
     for t in range(T):
         if policy == "random":
@@ -94,7 +94,7 @@ def run_lockstep(uamenv, oracle, B, N, T, policy="random", seed=123, check_state
         oo = orc.step(acts)
         where = "step %d" % t
         compare_outputs(g, oo, where, obs_tol)
-        counts += np.bincount(oo[3], minlength=4)
+        counts += np.bincount(oo[3], minlength=5)
         ost = orc.get_state()
         if check_state_every and (t % check_state_every == 0 or t == T - 1):
             compare_states(env.get_state(), ost, where, hold_sh=hold_sh)

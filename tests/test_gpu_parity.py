@@ -368,3 +368,59 @@ def test_monitor_episode_stats_match_oracle(uamenv, oracle):
         plain.episode_stats()
     plain.close()
     env.close()
+
+
+# ---------------------------------------------------------------- k-nearest observation / HER env
+@pytest.mark.parametrize("rng,precision,N", [("philox", "f32", 8), ("philox", "exact", 32), ("mt19937", "exact", 8),
+                                              ("philox", "f32", 80)])
+def test_her9_knn_obs_matches_oracle(uamenv, oracle, rng, precision, N):
+    pu.run_lockstep(uamenv, oracle, 160, N, 250, policy="goal", variant="her9", rng=rng, precision=precision,
+                    check_state_every=10)
+
+
+def test_her9_wall_termination_matches_oracle(uamenv, oracle):
+    class Cfg(uamenv.Config):
+        sparse_reward = True
+    out = pu.run_lockstep(uamenv, oracle, 256, 8, 400, policy="random", variant="her9", rng="philox", precision="f32",
+                          config=Cfg, check_state_every=10)
+    assert out["counts"].shape[0] >= 5 and out["counts"][4] > 0, "no wall termination exercised: %s" % out["counts"]
+
+
+@pytest.mark.parametrize("name", gu.HER_FIXTURES)
+def test_gpu_replays_her_fixture_from_seed(uamenv, name):
+    """The HER env's reference trajectories (k-nearest ordering, 'w' terminations) from np.random.seed(s) alone."""
+    fx = gu.load(name)
+    N = int(fx["meta_N"])
+    over = gu.config_overrides(fx)
+    env = uamenv.BatchedSingleAircraftEnv(1, N, variant="her9", rng="mt19937", precision="exact", seed=int(fx["meta_seed"]),
+                                          auto_reset=False, sparse_reward=over["sparse_reward"],
+                                          wall_terminates=over["wall_terminates"], knn=over["knn"])
+    env.reset()                       # the reference's constructor resets once
+    tol = 1e-5
+    obs0 = env.reset().cpu().numpy()[0]
+    assert np.abs(obs0 - fx["obs0"]).max() <= tol
+    reset_steps = {int(t): i for i, t in enumerate(fx["reset_steps"])}
+    for t in range(len(fx["actions"])):
+        obs, rew, done, infos = env.step(fx["actions"][t:t + 1])
+        where = "%s step %d" % (name, t)
+        assert bool(done[0].item()) == bool(fx["done"][t]) and int(infos.codes[0].item()) == int(fx["info"][t]), where
+        assert abs(float(rew[0].item()) - fx["reward"][t]) <= tol, where
+        assert np.abs(obs.cpu().numpy()[0] - fx["obs"][t]).max() <= tol, where + " obs"
+        if fx["done"][t]:
+            assert np.abs(env.reset().cpu().numpy()[0] - fx["reset_obs"][reset_steps[t]]).max() <= tol, where + " reset obs"
+    env.close()
+
+
+def test_her9_gym_class(uamenv):
+    fx = gu.load("g13_her9_n8_seed41")
+    env = uamenv.SingleAircraftDiscrete9HEREnv(num_intruders=8)
+    env.seed(41)
+    ob = env.reset()
+    assert set(ob) == {"observation", "achieved_goal", "desired_goal"} and ob["observation"].shape == (24,)
+    assert env.observation_space.shape == (26,)
+    flat = np.concatenate([ob["observation"], ob["achieved_goal"], ob["desired_goal"]])
+    assert np.abs(flat - fx["obs0"]).max() <= 1e-5
+    ob, r, d, info = env.step(int(fx["actions"][0]))
+    assert abs(r - fx["reward"][0]) <= 1e-5 and info == {"result": ""}
+    assert isinstance(env.compute_reward(ob["achieved_goal"], ob["desired_goal"], None), float)
+    env.close()

@@ -22,13 +22,15 @@ def _assert_state(orc_state, want, where):
                                  (where, k, bad[:4].tolist(), got[tuple(bad[0])], v[tuple(bad[0])]))
 
 
-@pytest.mark.parametrize("name", gu.TRAJECTORY_FIXTURES)
+@pytest.mark.parametrize("name", gu.TRAJECTORY_FIXTURES + gu.HER_FIXTURES)
 def test_oracle_replays_reference_bit_exact(oracle, name):
     fx = gu.load(name)
     N = int(fx["meta_N"])
     cfg = oracle.default_config(1, N, rng_mode=oracle.RNG_MT19937, precision=oracle.POS_EXACT, auto_reset=0,
                                 **gu.config_overrides(fx))
     env = oracle.OracleBatch(cfg, oracle.MATH_LIBM)
+    if name in gu.HER_FIXTURES:
+        env.reset()      # SingleAircraftDiscrete9HEREnv.__init__ calls self.reset() (Discrete9HEREnv.py:32)
     obs0 = env.reset()
     assert np.array_equal(obs0[0], fx["obs0"]), "reset obs differs"
     if "st0_int_x" in fx:
