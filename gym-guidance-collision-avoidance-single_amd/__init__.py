@@ -9,7 +9,8 @@ from . import _capi
 from ._capi import UamError, build, default_config
 from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2Env, SingleAircraftEnv,
                    SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv,
-                   SingleAircraftDiscrete9HEREnv, make_config)
+                   SingleAircraftDiscrete9HEREnv, SingleAircraftDiscrete3HEREnv, her_goal_reward,
+                   her_input_reward, make_config)
 from . import spaces
 from .sharded import ShardedSingleAircraftEnv, shard_bounds
 from .mcts import BatchedMCTS, mcts_config
@@ -17,6 +18,7 @@ from .mcts import BatchedMCTS, mcts_config
 __all__ = [
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
     "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv",
-    "SingleAircraftDiscrete9HEREnv", "make_config",
+    "SingleAircraftDiscrete9HEREnv", "SingleAircraftDiscrete3HEREnv", "her_goal_reward", "her_input_reward",
+    "make_config",
     "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds", "BatchedMCTS", "mcts_config",
 ]

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("UAMENV_LIB") or os.path.join(CSRC, "libuamenv_hip.so")   # UAMENV_LIB: development override
 
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
-ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1 = 0, 1, 2
+ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3 = 0, 1, 2, 3
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1
@@ -46,6 +46,7 @@ class UamConfig(C.Structure):
         ("own_x0", C.c_double), ("own_y0", C.c_double), ("own_speed0", C.c_double), ("own_heading0", C.c_double),
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
         ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
+        ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -107,6 +108,9 @@ SYMBOLS = [
     ("uam_step_many", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
+    ("uam_nearest", C.c_int, [_P, _P, _P]),
+    ("uam_her_goal_reward", C.c_int, [C.POINTER(UamConfig), C.c_int, _P, _P, C.c_int64, _P, _P]),
+    ("uam_her_input_reward", C.c_int, [C.POINTER(UamConfig), C.c_int, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     ("uam_episode_stats", C.c_int, [_P, _P, _P, _P]),
     ("uam_get_state", C.c_int, [_P, C.POINTER(UamStateView)]),
     ("uam_set_state", C.c_int, [_P, C.POINTER(UamStateView)]),

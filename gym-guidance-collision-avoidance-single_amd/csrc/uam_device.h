@@ -68,6 +68,7 @@ struct UamDev {
     double*  goal_y;
     int32_t* no_conflict;
     uint32_t* reset_count; /* [B] episodes started so far: Philox counter of the reset draws */
+    float*   nearest;   /* [B] distance to the nearest swept intruder of the last step (shaped_reward only) */
     float4*  share;     /* [B*3] OwnShare records handed from uam_own_kernel to uam_sweep_kernel */
     double*  ep_ret;    /* [B] running episode return / length and those of the last finished episode */
     int32_t* ep_len;
@@ -90,19 +91,22 @@ struct UamCold {
     double own_vx0, own_vy0;      /* float32(own_speed0 * cos/sin(own_heading0)), SingleAircraftEnv.py:275-277 */
     double sep2, nmac2, init2;    /* float64 squared-distance thresholds: min{v : sqrt(v) >= thr} */
     double wall_pen, inv_diag;    /* HER env family: wall penalty, 1/Config.diagonal */
+    double goal_lo, goal_span_x, goal_span_y;   /* goal = lo + span * u (np.random.uniform(low, high)) */
+    double near_thr, near_coeff;  /* 3 * minimum_separation, Config.conflict_coeff (Discrete3HEREnv.py:225-226) */
 };
 
 struct UamParams {
     UamDev s;
     const UamCold* c;
     int B, N, Np, Q, L, lshift, E, D;
-    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep, wall_term, knn;
+    int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep, wall_term, knn, shaped;
     uint32_t seed_lo, seed_hi, gid0;
     uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
     float W32, H32, vmax32, psig32;
     float sep2_32, nmac2_32, init2_32;   /* float32 squared-distance thresholds: min{v : sqrtf(v) >= thr} */
     float inv_W32, inv_H32, inv_vden32;  /* reciprocals for the normalised float32 obs */
     float nmac_pen32, conf_pen32;
+    float near_thr32, near_coeff32;      /* float32(3 * minimum_separation), float32(conflict_coeff) */
     float spawn_sx, spawn_sy, min_speed32, vrange32;   /* float32 spawn (lean Philox mode) */
     const double2* noise;         /* [B] (zh, zs) of this step, produced ahead by uam_noise_kernel (Philox) */
     /* per-call I/O (device pointers owned by the caller) */
@@ -651,7 +655,7 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     }
     double g1, g2;
     rng.two(true, UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
-    const double gx = 0.0 + p.c->W * g1, gy = 0.0 + p.c->H * g2;
+    const double gx = p.c->goal_lo + p.c->goal_span_x * g1, gy = p.c->goal_lo + p.c->goal_span_y * g2;
     /* every lane of the group has read reset_count above; the group is one wave-resident unit */
     __builtin_amdgcn_wave_barrier();
     if (gl == 0) {
@@ -701,6 +705,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     bool has_speed = true;
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
+    else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
     hd += c.d_heading * (a0 - 1.0);
     hd += 0.0 + c.heading_sigma * zh;
@@ -758,10 +763,12 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
  * hand the 48-byte records over through LDS, and one block barrier later everyone sweeps.  Saves the
  * separate launch (5.5 us of pure latency at B=65536).  Used by every Philox configuration; the threads
  * that run the ownship phase fetch their quad after it, so the phase never adds register pressure. */
-template <bool POS64, int RNG, bool RI, bool SH, bool ROS, bool FUSED>
+/* DYN: 0 straight-line intruders, 1 RandIntruder, 2 straight-line + the reward shaped by the nearest swept intruder */
+template <bool POS64, int RNG, int DYN, bool SH, bool ROS, bool FUSED>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     typedef typename PosT<POS64>::type P;
+    constexpr bool RI = DYN == 1, SHAPED = DYN == 2;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -832,10 +839,32 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* first NMAC index of the env: everything after it is untouched this step (:167-168) */
     const uint32_t kmin = grp_min(first_nmac, L);
     uint32_t packed = 0, resp = 0;
+    /* shaped reward only: nearest swept intruder (Discrete3HEREnv.py:185-191), measured like dist_flags.
+     * float32 positions: the minimum of the squared distances (sqrtf is monotonic), one sqrtf at the end */
+    double near_d = 9999.0;
+    float near_d2 = 9999.0f * 9999.0f;
+    uint32_t near_tag = 0;     /* (index + 1) << 1 | value-is-float64, of the intruder that set near_d */
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const uint32_t idx = 4u * gl + j;
         if (((validm >> j) & 1u) && idx <= kmin) {
+            if constexpr (SHAPED && !POS64) {
+                const float dx = ox - (float)nx[j], dy = oy - (float)ny[j];
+                near_d2 = fminf(near_d2, dx * dx + dy * dy);
+                near_tag = 2u;
+            }
+            if constexpr (SHAPED && POS64) {
+                const bool prom = (q.flags >> (4 + j)) & 1u;
+                double d;
+                if (prom) {
+                    const double dx = (double)ox - (double)nx[j], dy = (double)oy - (double)ny[j];
+                    d = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
+                } else {
+                    const float dx = ox - (float)nx[j], dy = oy - (float)ny[j];
+                    d = (double)__builtin_sqrtf(dx * dx + dy * dy);
+                }
+                if (!(near_d < d)) { near_d = d; near_tag = ((idx + 1u) << 1) | (prom ? 1u : 0u); }   /* min(d, nearest): ties keep d */
+            }
             if ((confm >> j) & 1u) {
                 packed += 0x10000u + (((q.flags >> j) & 1u) ? 0u : 1u);   /* first-time flag -> no_conflict += 1 */
                 q.flags |= 1u << j;
@@ -896,6 +925,33 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     else if (conf_any) { reward = p.conf_pen32; done = false; info = UAM_INFO_CONFLICT; }
     else if (tail_code) { reward = s0.z; done = true; info = tail_code == 2u ? UAM_INFO_WALL : UAM_INFO_GOAL; }
     else { reward = s0.z; done = false; info = UAM_INFO_NONE; }
+    if constexpr (SHAPED && !POS64) {
+        uint32_t any = near_tag;
+        for (int o = L >> 1; o > 0; o >>= 1) {
+            near_d2 = fminf(near_d2, __shfl_xor(near_d2, o));
+            any |= (uint32_t)__shfl_xor((int)any, o);
+        }
+        const float nf = any ? __builtin_sqrtf(near_d2) : 9999.0f;
+        /* :225-232: float32 distance -> float32 arithmetic (NEP 50) */
+        if (info == UAM_INFO_NONE && any && nf < p.near_thr32) reward = reward + (p.near_coeff32 * nf - 0.1f);
+        if (env_ok && gl == 0) p.s.nearest[env] = nf;
+    }
+    if constexpr (SHAPED && POS64) {
+        double gmin = near_d;
+        for (int o = L >> 1; o > 0; o >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, o));
+        uint32_t tag = near_d == gmin ? near_tag : 0u;       /* ties across lanes: the later intruder, as in the loop */
+        for (int o = L >> 1; o > 0; o >>= 1) tag = max(tag, (uint32_t)__shfl_xor((int)tag, o));
+        if (info == UAM_INFO_NONE && tag) {   /* :225-232, NEP-50 arithmetic on the distance's dtype */
+            if (tag & 1u) {
+                const double r = gmin < pk.c->near_thr ? pk.c->near_coeff * gmin - 0.1 : 0.0;
+                reward = (float)((double)reward + r);
+            } else {
+                const float nf = (float)gmin;
+                reward = nf < p.near_thr32 ? reward + (p.near_coeff32 * nf - 0.1f) : reward;
+            }
+        }
+        if (env_ok && gl == 0) p.s.nearest[env] = (float)gmin;
+    }
 
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
@@ -1170,7 +1226,54 @@ __global__ void uam_policy_kernel(const UamParams p)
     }
     if (p.action_mode == UAM_ACT_DISCRETE9) ((int32_t*)p.actions_out)[e] = a0 * 3 + a1;
     else if (p.action_mode == UAM_ACT_PAIR) ((int2*)p.actions_out)[e] = make_int2(a0, a1);
+    else if (p.action_mode == UAM_ACT_DISCRETE3) ((int32_t*)p.actions_out)[e] = a0;
     else ((float*)p.actions_out)[e] = ac;
+}
+
+/* ------------------------------------------------------------------ hindsight relabelling (stateless)
+ * compute_reward / compute_input_reward of the HER envs (Discrete9HEREnv.py:229-276), one row per thread,
+ * float64 arithmetic on the float32 inputs.  x ** 2 on a NumPy scalar is libm pow; here it is x * x (the
+ * portable-math convention of this library: differs by 1 ulp of the float64 distance in <0.1 % of rows). */
+struct UamHerParams {
+    double W, H, min_sep, nmac, goal_r, nmac_pen, conf_pen, step_pen, goal_rew, dense_div;
+    int sparse, knn, has_intruders, D;
+    long long M;
+    const float* a;      /* achieved [M,2] or inputs [M,D] */
+    const float* g;      /* desired [M,2] */
+    float* reward;
+    uint8_t* done;
+};
+
+__global__ void __launch_bounds__(256) uam_her_goal_reward_kernel(const UamHerParams p)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    const float2 a = ((const float2*)p.a)[i], g = ((const float2*)p.g)[i];
+    const double dx = (double)a.x * p.W - (double)g.x * p.W, dy = (double)a.y * p.H - (double)g.y * p.H;
+    const double d = __builtin_sqrt(dx * dx + dy * dy);      /* norm(axis=-1): plain products and sum */
+    p.reward[i] = d < p.goal_r ? (float)p.goal_rew : (p.sparse ? (float)p.step_pen : (float)(-d / p.dense_div));
+}
+
+__global__ void __launch_bounds__(256) uam_her_input_reward_kernel(const UamHerParams p)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.M) return;
+    const float* x = p.a + i * p.D;
+    const double ownx = (double)x[0] * p.W, owny = (double)x[1] * p.H;
+    const double gx = (double)x[p.D - 2] * p.W, gy = (double)x[p.D - 1] * p.H;
+    double dx = ownx - gx, dy = owny - gy;
+    const double dist_goal = __builtin_sqrt(dx * dx + dy * dy);
+    double rew = dist_goal < p.goal_r ? p.goal_rew : (p.sparse ? p.step_pen : -dist_goal / p.dense_div);
+    bool term = dist_goal < p.goal_r;
+    if (p.has_intruders) {
+        for (int idx = p.knn - 1; idx >= 0; idx--) {     /* the first hit in ascending idx wins: scan downwards, overwrite */
+            dx = ownx - (double)x[idx * 4 + 4] * p.W; dy = owny - (double)x[idx * 4 + 5] * p.H;
+            const double di = __builtin_sqrt(dx * dx + dy * dy);
+            if (di < p.min_sep) { const bool nm = di < p.nmac; rew = nm ? p.nmac_pen : p.conf_pen; term = nm; }
+        }
+    }
+    p.reward[i] = (float)rew;
+    if (p.done) p.done[i] = term ? 1 : 0;
 }
 
 #endif /* UAM_DEVICE_H */

@@ -91,6 +91,7 @@ extern "C" int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = pi / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
     c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
+    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->reserved1 = 0;
     return UAM_OK;
 }
 
@@ -111,7 +112,11 @@ static int validate(const uam_config* c)
         if (!(c->diagonal > 0)) return fail(UAM_EINVAL, "diagonal must be positive");
         if (c->dynamics == UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "UAM_OBS_KNN5 is not defined for the RandIntruder dynamics");
     }
-    if (c->action_mode < 0 || c->action_mode > UAM_ACT_CONTINUOUS1) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
+    if (c->action_mode < 0 || c->action_mode > UAM_ACT_DISCRETE3) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
+    if (!(c->goal_margin >= 0) || c->goal_margin * 2 >= fmin(c->window_width, c->window_height))
+        return fail(UAM_EINVAL, "goal_margin %g leaves no room for the goal", c->goal_margin);
+    if (c->shaped_reward && c->dynamics == UAM_DYN_RANDINTRUDER)
+        return fail(UAM_EINVAL, "shaped_reward is not defined for the RandIntruder dynamics");
     if (c->dynamics < 0 || c->dynamics > UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "bad dynamics %d", c->dynamics);
     if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
     if (c->precision < 0 || c->precision > UAM_POS_EXACT) return fail(UAM_EINVAL, "bad precision %d", c->precision);
@@ -187,6 +192,11 @@ static void fill_cold(const uam_config& c, UamCold* k)
     k->sep2 = sq_threshold_f64(c.minimum_separation); k->nmac2 = sq_threshold_f64(c.nmac_dist);
     k->init2 = sq_threshold_f64(c.initial_min_dist);
     k->wall_pen = c.wall_penalty; k->inv_diag = c.diagonal > 0 ? 1.0 / c.diagonal : 0.0;
+    /* np.random.uniform(low, high) = low + (high - low) * u, Discrete3HEREnv.py:349-353 (margin 0: random_pos) */
+    k->goal_lo = c.goal_margin;
+    k->goal_span_x = (c.window_width - c.goal_margin) - c.goal_margin;
+    k->goal_span_y = (c.window_height - c.goal_margin) - c.goal_margin;
+    k->near_thr = 3 * c.minimum_separation; k->near_coeff = c.conflict_coeff;
 }
 
 static void fill_params(const uam_env* e, UamParams* p)
@@ -202,6 +212,8 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->track_ep = c.track_episodes ? 1 : 0;
     p->wall_term = c.wall_terminates ? 1 : 0;
     p->knn = c.knn;
+    p->shaped = c.shaped_reward ? 1 : 0;
+    p->near_thr32 = (float)(3 * c.minimum_separation); p->near_coeff32 = (float)c.conflict_coeff;
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
@@ -304,6 +316,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.reset_count, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.share, (size_t)B * 3);
+    if (cfg->shaped_reward && !rc) rc = dev_alloc(e, &e->s.nearest, (size_t)B);
     if (cfg->track_episodes) {
         if (!rc) rc = dev_alloc(e, &e->s.ep_ret, (size_t)B);
         if (!rc) rc = dev_alloc(e, &e->s.ep_len, (size_t)B);
@@ -389,7 +402,7 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
 }
 
 /* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held, random ownship start) ---- */
-template <bool POS64, int RNG, bool RI, bool SH>
+template <bool POS64, int RNG, int RI, bool SH>
 static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t st)
 {
     dim3 grid(grid_of(e)), block(e->T);
@@ -409,9 +422,13 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
 template <bool POS64, int RNG>
 static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
 {
-    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, true, true>(e, p, st);
-    else if (e->hold_sh) launch_sweep_ros<POS64, RNG, false, true>(e, p, st);
-    else launch_sweep_ros<POS64, RNG, false, false>(e, p, st);
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, 1, true>(e, p, st);
+    else if (e->cfg.shaped_reward) {
+        if (e->hold_sh) launch_sweep_ros<POS64, RNG, 2, true>(e, p, st);
+        else launch_sweep_ros<POS64, RNG, 2, false>(e, p, st);
+    }
+    else if (e->hold_sh) launch_sweep_ros<POS64, RNG, 0, true>(e, p, st);
+    else launch_sweep_ros<POS64, RNG, 0, false>(e, p, st);
 }
 
 /* one env.step(): ownship kernel (thread per env) then the intruder sweep (lane group per env) */
@@ -577,6 +594,64 @@ extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)
     else if (x) hipLaunchKernelGGL((uam_observe_kernel<true, false>), grid, block, lds, (hipStream_t)stream, p);
     else if (e->hold_sh) hipLaunchKernelGGL((uam_observe_kernel<false, true>), grid, block, lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((uam_observe_kernel<false, false>), grid, block, lds, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+extern "C" int uam_nearest(uam_env* e, float* nearest_out_dev, void* stream)
+{
+    if (!e || !nearest_out_dev) return fail(UAM_EINVAL, "NULL argument");
+    if (!e->cfg.shaped_reward) return fail(UAM_EINVAL, "the nearest-intruder distance is only tracked with uam_config.shaped_reward = 1");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(nearest_out_dev, e->s.nearest, (size_t)e->cfg.num_envs * 4, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return UAM_OK;
+}
+
+static int her_params(const uam_config* c, UamHerParams* p)
+{
+    if (!c) return fail(UAM_EINVAL, "cfg is NULL");
+    if (c->struct_size != sizeof(uam_config))
+        return fail(UAM_EINVAL, "uam_config.struct_size %u != %zu (ABI mismatch)", c->struct_size, sizeof(uam_config));
+    if (!(c->window_width > 0) || !(c->window_height > 0)) return fail(UAM_EINVAL, "window must be positive");
+    memset(p, 0, sizeof(*p));
+    p->W = c->window_width; p->H = c->window_height; p->min_sep = c->minimum_separation; p->nmac = c->nmac_dist;
+    p->goal_r = c->goal_radius; p->nmac_pen = c->nmac_penalty; p->conf_pen = c->conflict_penalty;
+    p->step_pen = c->step_penalty; p->goal_rew = c->goal_reward; p->dense_div = c->dense_reward_div;
+    p->sparse = c->sparse_reward ? 1 : 0; p->knn = c->knn; p->has_intruders = c->num_intruders != 0;
+    return UAM_OK;
+}
+
+extern "C" int uam_her_goal_reward(const uam_config* cfg, int device, const float* achieved_dev, const float* desired_dev,
+                                   int64_t M, float* reward_out_dev, void* stream)
+{
+    UamHerParams p;
+    int rc = her_params(cfg, &p);
+    if (rc) return rc;
+    if (M < 0 || !reward_out_dev || ((!achieved_dev || !desired_dev) && M)) return fail(UAM_EINVAL, "NULL argument");
+    if (((uintptr_t)achieved_dev | (uintptr_t)desired_dev) & 7u) return fail(UAM_EINVAL, "goal arrays must be 8-byte aligned");
+    if (M == 0) return UAM_OK;
+    HIP_TRY(hipSetDevice(device));
+    p.M = M; p.a = achieved_dev; p.g = desired_dev; p.reward = reward_out_dev;
+    hipLaunchKernelGGL(uam_her_goal_reward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+extern "C" int uam_her_input_reward(const uam_config* cfg, int device, const float* inputs_dev, int64_t M, int32_t D,
+                                    float* reward_out_dev, uint8_t* done_out_dev, void* stream)
+{
+    UamHerParams p;
+    int rc = her_params(cfg, &p);
+    if (rc) return rc;
+    if (M < 0 || !reward_out_dev || (!inputs_dev && M)) return fail(UAM_EINVAL, "NULL argument");
+    /* the upstream indexing touches columns 4*idx+4, 4*idx+5 for idx < knn, and the last two */
+    if (cfg->knn < 0 || D < 4 || (p.has_intruders && D < 4 * cfg->knn + 2))
+        return fail(UAM_EINVAL, "row width D=%d too small for knn=%d", D, cfg->knn);
+    if (M == 0) return UAM_OK;
+    HIP_TRY(hipSetDevice(device));
+    p.M = M; p.D = D; p.a = inputs_dev; p.reward = reward_out_dev; p.done = done_out_dev;
+    hipLaunchKernelGGL(uam_her_input_reward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }

@@ -65,6 +65,7 @@ _VARIANTS = {
     "randintruder": (capi.OBS_RAW6, capi.ACT_PAIR, capi.DYN_RANDINTRUDER, 0),    # ...MCTSRandIntruderEnv.py
     "random_start": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),  # Simulators/SingleAircraftRandomEnv.py
     "her9": (capi.OBS_KNN5, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),           # ...Discrete9HEREnv.py (k-nearest obs)
+    "her3": (capi.OBS_KNN5, capi.ACT_DISCRETE3, capi.DYN_STRAIGHT, 1),           # ...Discrete3HEREnv.py (+ shaped reward)
 }
 _RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
 _PREC = {"f32": capi.POS_F32, "exact": capi.POS_EXACT}
@@ -90,7 +91,10 @@ def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox",
         step_penalty=config.step_penalty, goal_reward=config.goal_reward,
         own_speed0=config.min_speed, wall_penalty=config.wall_penalty, diagonal=config.diagonal, knn=int(config.n),
         # the HER env ends the episode when the ownship leaves the map, but only under sparse_reward (:217-221)
-        wall_terminates=int(variant == "her9" and bool(config.sparse_reward)))
+        wall_terminates=int(variant in ("her9", "her3") and bool(config.sparse_reward)),
+        conflict_coeff=config.conflict_coeff,
+        # Discrete3HEREnv.py: goal 100 px inside the map (:349-353), reward shaped by the nearest intruder (:225-232)
+        goal_margin=100.0 if variant == "her3" else 0.0, shaped_reward=int(variant == "her3"))
     for k, v in overrides.items():
         if not hasattr(cfg, k):
             raise AttributeError("uam_config has no field %r" % k)
@@ -162,7 +166,7 @@ class BatchedSingleAircraftEnv:
         if self.cfg.action_mode == capi.ACT_CONTINUOUS1:
             self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float64)
         else:
-            self.action_space = spaces.Discrete(9)
+            self.action_space = spaces.Discrete(3 if self.cfg.action_mode == capi.ACT_DISCRETE3 else 9)
         self._h = C.c_void_p()
         capi.check(self._lib.uam_create(C.byref(self.cfg), self.device.index, C.byref(self._h)))
         B, D = self.num_envs, self.obs_dim
@@ -300,6 +304,13 @@ class BatchedSingleAircraftEnv:
         ln = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
         capi.check(self._lib.uam_episode_stats(self._h, ret.data_ptr(), ln.data_ptr(), self._stream()))
         return ret, ln
+
+    def nearest(self):
+        """float32[B]: distance to the nearest intruder swept by the last step (variant "her3": what
+        Discrete3HEREnv.step returns as its 4th value)."""
+        out = self._torch.empty((self.num_envs,), dtype=self._torch.float32, device=self.device)
+        capi.check(self._lib.uam_nearest(self._h, out.data_ptr(), self._stream()))
+        return out
 
     @property
     def no_conflict(self):
@@ -491,3 +502,54 @@ class SingleAircraftDiscrete9HEREnv(SingleAircraftEnv):
         if dist_goal < self.goal_radius:
             return c.goal_reward
         return c.step_penalty if c.sparse_reward else -dist_goal / 1200
+
+
+class SingleAircraftDiscrete3HEREnv(SingleAircraftDiscrete9HEREnv):
+    """Simulators/SingleAircraftDiscrete3HEREnv.py: three heading actions, goal drawn 100 px inside the map,
+    step reward shaped by the nearest intruder; step() returns that distance in place of the info dict (:178)."""
+    _variant = "her3"
+
+    def step(self, action):
+        obs, rew, done, _ = self._vec.step([int(action)])
+        return self._obs_np(obs), float(rew[0].item()), bool(done[0].item()), float(self._vec.nearest()[0].item())
+
+
+def _her_cfg(config, sparse_reward, knn, num_intruders):
+    n = int(config.intruder_size if num_intruders is None else num_intruders)
+    cfg = make_config(1, max(n, 1), config=config)
+    cfg.num_intruders = n        # 0 skips the intruder test (Config.intruder_size != 0, :256)
+    cfg.knn = int(config.n if knn is None else knn)
+    if sparse_reward is not None:
+        cfg.sparse_reward = int(bool(sparse_reward))
+    return cfg
+
+
+def her_goal_reward(achieved_goal, desired_goal, config=Config, sparse_reward=None):
+    """Batched compute_reward (Discrete9HEREnv.py:229-243): float32 device tensors [M, 2] -> reward float32[M]."""
+    import torch
+    a = achieved_goal.contiguous().to(torch.float32)
+    g = desired_goal.contiguous().to(torch.float32)
+    if a.shape != g.shape or a.dim() != 2 or a.shape[1] != 2 or not a.is_cuda:
+        raise ValueError("achieved_goal / desired_goal must be device tensors of shape [M, 2]")
+    out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    cfg = _her_cfg(config, sparse_reward, None, None)
+    capi.check(capi.lib().uam_her_goal_reward(C.byref(cfg), a.device.index or 0, a.data_ptr(), g.data_ptr(), a.shape[0],
+                                              out.data_ptr(), torch.cuda.current_stream(a.device).cuda_stream))
+    return out
+
+
+def her_input_reward(new_inputs, config=Config, sparse_reward=None, knn=None, num_intruders=None):
+    """Batched compute_input_reward (Discrete9HEREnv.py:245-276) for hindsight relabelling
+    (Algorithms/pytorch/agent_her.py:105-117): rows observation | goal, float32 device tensor [M, D] ->
+    (reward float32[M], done bool[M]) with done = reward is the goal reward or the NMAC penalty."""
+    import torch
+    x = new_inputs.contiguous().to(torch.float32)
+    if x.dim() != 2 or not x.is_cuda:
+        raise ValueError("new_inputs must be a device tensor of shape [M, D]")
+    rew = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    done = torch.empty((x.shape[0],), dtype=torch.uint8, device=x.device)
+    cfg = _her_cfg(config, sparse_reward, knn, num_intruders)
+    capi.check(capi.lib().uam_her_input_reward(C.byref(cfg), x.device.index or 0, x.data_ptr(), x.shape[0], x.shape[1],
+                                               rew.data_ptr(), done.data_ptr(),
+                                               torch.cuda.current_stream(x.device).cuda_stream))
+    return rew, done.view(torch.bool)

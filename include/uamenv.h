@@ -64,7 +64,9 @@ enum {
 enum {
     UAM_ACT_DISCRETE9   = 0, /* int32[B]; a0 = a/3, a1 = a%3            SingleAircraftEnv.py:128-131 */
     UAM_ACT_PAIR        = 1, /* int32[B,2]; (a0, a1) used un-decoded     SingleAircraftMCTSEnv.py:126-134 */
-    UAM_ACT_CONTINUOUS1 = 2  /* float32[B]; heading += d_heading*(a-1), no speed command  SingleAircraft2Env.py:294-298 */
+    UAM_ACT_CONTINUOUS1 = 2, /* float32[B]; heading += d_heading*(a-1), no speed command  SingleAircraft2Env.py:294-298 */
+    UAM_ACT_DISCRETE3   = 3  /* int32[B] in {0,1,2}; heading += d_heading*(a-1), no speed command
+                                SingleAircraftDiscrete3HEREnv.py:43,406-414 */
 };
 
 /* ---- intruder dynamics ---- */
@@ -128,6 +130,12 @@ typedef struct uam_config {
     int32_t knn;               /* Config.n, nearest intruders in the UAM_OBS_KNN5 observation, config.py:55 */
     int32_t wall_terminates;   /* 1: out-of-map ownship ends the episode with wall_penalty (the reference does this
                                   only when sparse_reward is set, Discrete9HEREnv.py:217-221) */
+    /* SingleAircraftDiscrete3HEREnv.py */
+    double conflict_coeff;     /* Config.conflict_coeff, config.py:43 */
+    double goal_margin;        /* goal drawn in [m, W-m] x [m, H-m]: 100 in random_goal_pos (:349-353), 0 elsewhere */
+    int32_t shaped_reward;     /* 1: the non-terminal step reward gets + (conflict_coeff * d - 0.1) when the nearest swept
+                                  intruder is closer than 3 * minimum_separation (:225-232) */
+    int32_t reserved1;
 } uam_config;
 
 /* HOST-side view used by uam_get_state / uam_set_state (checkpoint, parity
@@ -203,12 +211,33 @@ int uam_observe(uam_env* env, float* obs_out, void* stream);
  * ret_out double[B], len_out int32[B], device. */
 int uam_episode_stats(uam_env* env, double* ret_out_dev, int32_t* len_out_dev, void* stream);
 
+/* Distance from the ownship to the nearest intruder swept by the LAST uam_step (float32[B], device): what
+ * SingleAircraftDiscrete3HEREnv.step returns in place of the info dict (:178, :185-191).  Measured after the
+ * intruders moved and before any respawn; on an NMAC step only the intruders up to the colliding one count.
+ * Needs uam_config.shaped_reward = 1 (the only mode that tracks it). */
+int uam_nearest(uam_env* env, float* nearest_out_dev, void* stream);
+
 /* Copy env.no_conflict (int32[B]) to a device buffer. */
 int uam_counters(uam_env* env, int32_t* no_conflict_out_dev, void* stream);
 
 /* Synchronous host<->device state exchange (see uam_state_view). */
 int uam_get_state(uam_env* env, uam_state_view* view);
 int uam_set_state(uam_env* env, const uam_state_view* view);
+
+/* Hindsight relabelling, stateless, M rows per launch, device pointers:
+ *   uam_her_goal_reward : compute_reward(achieved_goal, desired_goal)   Discrete9HEREnv.py:229-243 / Discrete3HEREnv.py:234-247
+ *                         achieved/desired float32[M,2] normalised positions -> reward float32[M]
+ *   uam_her_input_reward: compute_input_reward(new_inputs)              Discrete9HEREnv.py:245-276 / Discrete3HEREnv.py:249-278
+ *                         inputs float32[M,D] = observation (4 + 5*knn) | goal (2), D = 4 + 5*knn + 2;
+ *                         reward float32[M]; done uint8[M] or NULL = (reward is goal_reward or nmac_penalty), the
+ *                         test Algorithms/pytorch/agent_her.py:116-117 applies to the relabelled transition.
+ * The reference reads intruder idx at columns 4*idx+4, 4*idx+5 of a 5-wide record (so it mixes fields for
+ * idx >= 1); that indexing is reproduced, not corrected.  Uses cfg's window, thresholds, rewards,
+ * sparse_reward, knn, num_intruders (0 = skip the intruder test). */
+int uam_her_goal_reward(const uam_config* cfg, int device, const float* achieved_dev, const float* desired_dev,
+                        int64_t M, float* reward_out_dev, void* stream);
+int uam_her_input_reward(const uam_config* cfg, int device, const float* inputs_dev, int64_t M, int32_t D,
+                         float* reward_out_dev, uint8_t* done_out_dev, void* stream);
 
 /* Built-in policies for benchmarks / smoke runs (device, stream-ordered).
  *   kind 0: uniform random action from Philox(seed=policy_seed; env, call#)

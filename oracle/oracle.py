@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
-ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1 = 0, 1, 2
+ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3 = 0, 1, 2, 3
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1
@@ -40,6 +40,7 @@ class UamConfig(C.Structure):
         ("own_x0", C.c_double), ("own_y0", C.c_double), ("own_speed0", C.c_double), ("own_heading0", C.c_double),
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
         ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
+        ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -143,6 +144,11 @@ def lib():
         L.orc_get_state.argtypes = [C.c_void_p, C.POINTER(UamStateView)]
         L.orc_set_state.argtypes = [C.c_void_p, C.POINTER(UamStateView)]
         L.orc_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_nearest.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_her_goal_reward.restype = C.c_double
+        L.orc_her_goal_reward.argtypes = [C.POINTER(UamConfig), C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_her_input_reward.restype = C.c_double
+        L.orc_her_input_reward.argtypes = [C.POINTER(UamConfig), C.c_int, C.c_void_p, C.c_int]
         L.orc_spawn_count.restype = C.c_int64
         L.orc_spawn_count.argtypes = [C.c_void_p]
         L.orc_redraw_count.restype = C.c_int64
@@ -252,6 +258,12 @@ class OracleBatch:
         lib().orc_episode_stats(self._h, ret.ctypes.data, ln.ctypes.data)
         return ret, ln
 
+    def nearest(self):
+        """(distance to the nearest swept intruder of the last step, value-was-float64 flag)."""
+        d, f = np.zeros(self.B), np.zeros(self.B, dtype=np.uint8)
+        lib().orc_nearest(self._h, d.ctypes.data, f.ctypes.data)
+        return d, f
+
     @property
     def spawn_count(self):
         return lib().orc_spawn_count(self._h)
@@ -306,6 +318,19 @@ def mcts_config(N, **over):
             raise AttributeError(k)
         setattr(cfg, k, v)
     return cfg
+
+
+def her_goal_reward(cfg, achieved, desired):
+    """compute_reward(achieved_goal, desired_goal) row by row (float64)."""
+    a, g = np.asarray(achieved, dtype=np.float64).reshape(-1, 2), np.asarray(desired, dtype=np.float64).reshape(-1, 2)
+    return np.asarray([lib().orc_her_goal_reward(C.byref(cfg), a[i, 0], a[i, 1], g[i, 0], g[i, 1]) for i in range(len(a))])
+
+
+def her_input_reward(cfg, inputs, math_impl=MATH_LIBM):
+    """compute_input_reward(new_inputs) row by row (float64)."""
+    x = np.ascontiguousarray(inputs, dtype=np.float64)
+    x = x.reshape(-1, x.shape[-1])
+    return np.asarray([lib().orc_her_input_reward(C.byref(cfg), math_impl, x[i].ctypes.data, x.shape[1]) for i in range(len(x))])
 
 
 def mcts_move(cfg, state, action, rng_mode=RNG_MT19937, math_impl=MATH_LIBM, np_seed=0, root_id=0, sim=0, move=0):

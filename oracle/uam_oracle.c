@@ -138,6 +138,8 @@ typedef struct {
     uint32_t reset_count;           /* episodes started so far: Philox counter of the reset draws */
     mt_state* mt;                   /* own stream, or the shared one */
     int64_t spawns, redraws;
+    double nearest;                 /* dist_nearest_intruder of the last step (Discrete3HEREnv.py:185-191) */
+    int nearest_f64;                /* ... and whether that value was a float64 (promoted intruder) */
     double ep_ret, ep_last_ret;     /* Monitor accumulators, baselines/bench/monitor.py:58-75 */
     int32_t ep_len, ep_last_len;
 } env_t;
@@ -332,13 +334,15 @@ static void env_reset(const ctx_t* c)
     e->own_v_f32 = 1;
     for (int i = 0; i < c->b->N; i++) spawn_intruder(c, i, 1, &e->in[i]);
     if (g->rng_mode == UAM_RNG_MT19937) {    /* Goal(position=self.random_pos()), :91 */
-        e->goal_x = 0.0 + g->window_width * mt_double(e->mt);
-        e->goal_y = 0.0 + g->window_height * mt_double(e->mt);
+        /* np.random.uniform(low, high) = low + (high - low) * u; low = margin (0, or 100 in random_goal_pos,
+         * Discrete3HEREnv.py:349-353) */
+        e->goal_x = g->goal_margin + ((g->window_width - g->goal_margin) - g->goal_margin) * mt_double(e->mt);
+        e->goal_y = g->goal_margin + ((g->window_height - g->goal_margin) - g->goal_margin) * mt_double(e->mt);
     } else {
         uint32_t w[4];
         philox(c, PH_RESET_GOAL, 0, 0, w);
-        e->goal_x = 0.0 + g->window_width * u32d(w[0]);
-        e->goal_y = 0.0 + g->window_height * u32d(w[1]);
+        e->goal_x = g->goal_margin + ((g->window_width - g->goal_margin) - g->goal_margin) * u32d(w[0]);
+        e->goal_y = g->goal_margin + ((g->window_height - g->goal_margin) - g->goal_margin) * u32d(w[1]);
     }
     e->no_conflict = 0;
     e->reset_count++;
@@ -477,6 +481,9 @@ static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info
     env_t* e = c->e;
     int conflict = 0;
     const float psig32 = (float)g->position_sigma;
+    double nearest = 9999.0;     /* self.dist_nearest_intruder = 9999, Discrete3HEREnv.py:185 */
+    int nearest_f64 = 0, nearest_set = 0;
+    e->nearest = nearest; e->nearest_f64 = 0;
     for (int idx = 0; idx < b->N; idx++) {
         intruder_t* it = &e->in[idx];
         intruder_t old;
@@ -486,6 +493,9 @@ static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info
         if (!it->promoted) { it->x = (double)(float)((float)it->x + ax); it->y = (double)(float)((float)it->y + ay); }
         else { it->x = it->x + (double)ax; it->y = it->y + (double)ay; }
         double d = dist_own_intruder(e, it);
+        /* min(dist_intruder, self.dist_nearest_intruder), :191: Python's min keeps its first argument on ties */
+        if (!(nearest < d)) { nearest = d; nearest_f64 = it->promoted; nearest_set = 1; }
+        e->nearest = nearest; e->nearest_f64 = nearest_f64;
         old = *it;
         /* position_range.contains: inclusive bounds, :151 */
         int inside = (it->x >= 0.0) && (it->y >= 0.0) && (it->x <= (double)(float)g->window_width) &&
@@ -512,6 +522,22 @@ static void terminal_reward(const ctx_t* c, double* reward, int* done, int* info
     }
     double dg = dist_own_goal(e);
     if (dg < g->goal_radius) { *reward = g->goal_reward; *done = 1; *info = UAM_INFO_GOAL; return; } /* :179-180 */
+    if (g->shaped_reward && nearest_set) {   /* Discrete3HEREnv.py:225-232, NEP-50 arithmetic on the distance's dtype */
+        if (!nearest_f64) {
+            const float nf = (float)nearest;
+            const float r = nf < (float)(3 * g->minimum_separation)
+                                ? (float)((float)((float)g->conflict_coeff * nf) - (float)0.1) : 0.0f;
+            const int shaped = nf < (float)(3 * g->minimum_separation);   /* r is a float32 only on this branch; else int 0 */
+            if (g->sparse_reward) *reward = shaped ? (double)(float)((float)g->step_penalty + r) : g->step_penalty + 0;
+            else *reward = -dg / g->dense_reward_div + (double)r;
+        } else {
+            const double r = nearest < 3 * g->minimum_separation ? g->conflict_coeff * nearest - 0.1 : 0.0;
+            if (g->sparse_reward) *reward = g->step_penalty + r;
+            else *reward = -dg / g->dense_reward_div + r;
+        }
+        *done = 0; *info = UAM_INFO_NONE;
+        return;
+    }
     if (g->sparse_reward) { *reward = g->step_penalty; *done = 0; *info = UAM_INFO_NONE; return; }   /* :182-183 */
     *reward = -dg / g->dense_reward_div; *done = 0; *info = UAM_INFO_NONE;                           /* :185 */
 }
@@ -563,6 +589,9 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
     } else if (g->action_mode == UAM_ACT_PAIR) {
         a0 = (double)((const int32_t*)actions)[2 * eidx];
         a1 = (double)((const int32_t*)actions)[2 * eidx + 1];
+    } else if (g->action_mode == UAM_ACT_DISCRETE3) {
+        a0 = (double)((const int32_t*)actions)[eidx];        /* Discrete3HEREnv.py:408: heading += d_heading * (a - 1) */
+        has_speed = 0;
     } else {
         a0 = (double)((const float*)actions)[eidx];
         has_speed = 0;
@@ -581,6 +610,45 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
     reward[eidx] = r;
     done[eidx] = (uint8_t)d;
     if (info) info[eidx] = (uint8_t)inf;
+}
+
+/* ------------------------------------------------------------------ hindsight relabelling
+ * compute_reward, Discrete9HEREnv.py:229-243 = Discrete3HEREnv.py:234-247: float64 positions, np.linalg.norm. */
+double orc_her_goal_reward(const uam_config* g, double ax, double ay, double gx, double gy)
+{
+    const double dx = ax * g->window_width - gx * g->window_width, dy = ay * g->window_height - gy * g->window_height;
+    /* np.linalg.norm(v, axis=-1) is sqrt(add.reduce(v * v)): plain products and sum, not the BLAS dot form */
+    const double d = sqrt(dx * dx + dy * dy);
+    if (d < g->goal_radius) return g->goal_reward;
+    return g->sparse_reward ? g->step_penalty : -d / g->dense_reward_div;
+}
+
+/* compute_input_reward, Discrete9HEREnv.py:245-276 = Discrete3HEREnv.py:249-278: Python floats, metric() =
+ * math.sqrt(dx ** 2 + dy ** 2) (:423-426; float ** 2 is libm pow).  Columns 4*idx+4/5 as upstream. */
+double orc_her_input_reward(const uam_config* g, int math_impl, const double* x, int D)
+{
+    const double ownx = x[0] * g->window_width, owny = x[1] * g->window_height;
+    const double gx = x[D - 2] * g->window_width, gy = x[D - 1] * g->window_height;
+    double dx = ownx - gx, dy = owny - gy;
+    const double dist_goal = math_impl == ORC_MATH_LIBM ? sqrt(pow(dx, 2.0) + pow(dy, 2.0)) : sqrt(dx * dx + dy * dy);
+    if (g->num_intruders != 0) {
+        for (int idx = 0; idx < g->knn; idx++) {
+            const double ix = x[idx * 4 + 4] * g->window_width, iy = x[idx * 4 + 5] * g->window_height;
+            dx = ownx - ix; dy = owny - iy;
+            const double di = math_impl == ORC_MATH_LIBM ? sqrt(pow(dx, 2.0) + pow(dy, 2.0)) : sqrt(dx * dx + dy * dy);
+            if (di < g->minimum_separation) return di < g->nmac_dist ? g->nmac_penalty : g->conflict_penalty;
+        }
+    }
+    if (dist_goal < g->goal_radius) return g->goal_reward;
+    return g->sparse_reward ? g->step_penalty : -dist_goal / g->dense_reward_div;
+}
+
+void orc_nearest(const orc_batch* b, double* out, uint8_t* is_f64_out)
+{
+    for (int e = 0; e < b->B; e++) {
+        out[e] = b->env[e].nearest;
+        if (is_f64_out) is_f64_out[e] = (uint8_t)b->env[e].nearest_f64;
+    }
 }
 
 /* ------------------------------------------------------------------ batch API */
@@ -814,6 +882,7 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = M_PI / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
     c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
+    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->reserved1 = 0;
     return 0;
 }
 #endif

@@ -45,6 +45,9 @@ void orc_observe(orc_batch* b, double* obs_out);
 void orc_get_state(orc_batch* b, uam_state_view* v);
 void orc_set_state(orc_batch* b, const uam_state_view* v);
 void orc_episode_stats(const orc_batch* b, double* ret_out, int32_t* len_out);
+void orc_nearest(const orc_batch* b, double* out, uint8_t* is_f64_out);   /* Discrete3HEREnv.step's 4th return value */
+double orc_her_goal_reward(const uam_config* cfg, double ax, double ay, double gx, double gy);
+double orc_her_input_reward(const uam_config* cfg, int math_impl, const double* row, int D);
 int64_t orc_spawn_count(const orc_batch* b);  /* intruder (re)spawns so far */
 int64_t orc_redraw_count(const orc_batch* b); /* rejection redraws so far */
 

@@ -15,7 +15,8 @@ TRAJECTORY_FIXTURES = [
 
 # SingleAircraftDiscrete9HEREnv (k-nearest observation, random ownship start, optional wall termination);
 # its __init__ runs one reset() before the recorded one
-HER_FIXTURES = ["g13_her9_n8_seed41", "g13_her9_n32_seed42", "g13_her9_sparse_n8_seed43"]
+HER_FIXTURES = ["g13_her9_n8_seed41", "g13_her9_n32_seed42", "g13_her9_sparse_n8_seed43",
+                "g14_her3_n8_seed51", "g14_her3_n32_seed52", "g14_her3_sparse_n8_seed53", "g14_her3_straight_n80_seed54"]
 
 STATE_KEYS = ["int_x", "int_y", "int_vx", "int_vy", "int_speed", "int_heading", "int_conflict", "int_promoted",
               "own_x", "own_y", "own_heading", "own_speed", "own_vx", "own_vy", "goal_x", "goal_y", "no_conflict"]
@@ -39,6 +40,9 @@ def config_overrides(fx, **extra):
     if int(fx["meta_obs_mode"]) == 3:   # HER family
         sparse = int(fx["meta_sparse_reward"])
         over.update(knn=int(fx["meta_knn"]), random_own_start=1, sparse_reward=sparse, wall_terminates=sparse)
+        if "meta_shaped_reward" in fx:   # Discrete3HER
+            over.update(shaped_reward=int(fx["meta_shaped_reward"]), goal_margin=float(fx["meta_goal_margin"]),
+                        conflict_coeff=float(fx["meta_conflict_coeff"]))
     over.update(extra)
     return over
 

@@ -24,6 +24,8 @@ def goal_seek_actions(st, d_heading, action_mode):
         return a0 * 3 + a1
     if action_mode == 1:
         return np.stack([a0, a1], axis=1).astype(np.int32)
+    if action_mode == 3:
+        return a0
     return np.clip(1.0 + diff / d_heading, -1, 1).astype(np.float32)
 
 
@@ -32,6 +34,8 @@ def random_actions(rs, B, action_mode):
         return rs.randint(0, 9, size=B).astype(np.int32)
     if action_mode == 1:
         return rs.randint(0, 3, size=(B, 2)).astype(np.int32)
+    if action_mode == 3:
+        return rs.randint(0, 3, size=B).astype(np.int32)
     return rs.uniform(-1, 1, size=B).astype(np.float32)
 
 
@@ -50,12 +54,15 @@ def compare_states(gs, os_, where, fields=None, hold_sh=False):
                                  (where, k, len(bad), i, a[i], b[i]))
 
 
-def compare_outputs(g, o, where, obs_tol):
+def compare_outputs(g, o, where, obs_tol, reward_tol=0.0):
     gobs, grew, gdone, ginfo = g
     oobs, orew, odone, oinfo = o
     assert np.array_equal(gdone.astype(np.uint8), odone), where + ": done flags differ at %s" % np.argwhere(gdone != odone)[:4].tolist()
     assert np.array_equal(ginfo, oinfo), where + ": info codes differ at %s" % np.argwhere(ginfo != oinfo)[:4].tolist()
-    assert np.array_equal(grew, orew.astype(np.float32)), where + ": rewards differ (max |d| = %g)" % np.abs(grew - orew).max()
+    if reward_tol:
+        assert (np.abs(grew - orew) <= reward_tol).all(), where + ": rewards differ (max |d| = %g)" % np.abs(grew - orew).max()
+    else:
+        assert np.array_equal(grew, orew.astype(np.float32)), where + ": rewards differ (max |d| = %g)" % np.abs(grew - orew).max()
     if gobs is not None:
         d = np.abs(gobs.astype(np.float64) - oobs)
         lim = obs_tol * np.maximum(1.0, np.abs(oobs))
@@ -63,7 +70,7 @@ def compare_outputs(g, o, where, obs_tol):
 
 
 def run_lockstep(uamenv, oracle, B, N, T, policy="random", seed=123, check_state_every=1, obs_tol=1e-6,
-                 act_seed=7, **cfg_kw):
+                 act_seed=7, reward_tol=0.0, **cfg_kw):
     """Step GPU env and oracle in lockstep for T steps; every comparison is against the oracle on the SAME
     inputs.  Returns summary counters (dones per code, spawns) so tests can assert coverage."""
     env = uamenv.BatchedSingleAircraftEnv(B, N, seed=seed, **cfg_kw)
@@ -93,7 +100,10 @@ def run_lockstep(uamenv, oracle, B, N, T, policy="random", seed=123, check_state
         g = (o.cpu().numpy(), r_.cpu().numpy(), dn.cpu().numpy(), inf.codes.cpu().numpy())
         oo = orc.step(acts)
         where = "step %d" % t
-        compare_outputs(g, oo, where, obs_tol)
+        compare_outputs(g, oo, where, obs_tol, reward_tol)
+        if env.cfg.shaped_reward:     # Discrete3HEREnv.step's 4th return value
+            gn, (on, _) = env.nearest().cpu().numpy(), orc.nearest()
+            assert (np.abs(gn - on) <= 1e-6 * np.maximum(1.0, on)).all(), where + ": nearest-intruder distance differs"
         counts += np.bincount(oo[3], minlength=5)
         ost = orc.get_state()
         if check_state_every and (t % check_state_every == 0 or t == T - 1):

@@ -386,7 +386,7 @@ def test_her9_wall_termination_matches_oracle(uamenv, oracle):
     assert out["counts"].shape[0] >= 5 and out["counts"][4] > 0, "no wall termination exercised: %s" % out["counts"]
 
 
-@pytest.mark.parametrize("name", gu.HER_FIXTURES)
+@pytest.mark.parametrize("name", [n for n in gu.HER_FIXTURES if n.startswith("g13_")])
 def test_gpu_replays_her_fixture_from_seed(uamenv, name):
     """The HER env's reference trajectories (k-nearest ordering, 'w' terminations) from np.random.seed(s) alone."""
     fx = gu.load(name)
@@ -424,3 +424,85 @@ def test_her9_gym_class(uamenv):
     assert abs(r - fx["reward"][0]) <= 1e-5 and info == {"result": ""}
     assert isinstance(env.compute_reward(ob["achieved_goal"], ob["desired_goal"], None), float)
     env.close()
+
+
+# ---------------------------------------------------------------- Discrete3HER env: 3 actions, shaped reward, goal margin
+@pytest.mark.parametrize("rng,precision,N,sparse", [("philox", "f32", 8, False), ("philox", "f32", 32, True),
+                                                     ("philox", "exact", 8, False), ("mt19937", "exact", 8, True),
+                                                     ("mt19937", "f32", 80, False)])
+def test_her3_shaped_reward_matches_oracle(uamenv, oracle, rng, precision, N, sparse):
+    """Sparse: the float32 shaping is the reference's own arithmetic -> rewards bit-exact; dense: the GPU adds the
+    shaping to the float32 dense term instead of rounding the float64 sum once -> <= 1 float32 ulp (tolerance 1e-6)."""
+    class Cfg(uamenv.Config):
+        sparse_reward = sparse
+    out = pu.run_lockstep(uamenv, oracle, 192, N, 300, policy="mixed", variant="her3", rng=rng, precision=precision,
+                          config=Cfg, check_state_every=10, reward_tol=0.0 if sparse else 1e-6)
+    assert out["counts"][1] > 0 and out["counts"][3] > 0, out["counts"]
+
+
+@pytest.mark.parametrize("name", [n for n in gu.HER_FIXTURES if n.startswith("g14_")])
+def test_gpu_replays_her3_fixture_from_seed(uamenv, name):
+    """Discrete3HER reference trajectories from np.random.seed(s) alone: obs, shaped rewards, codes, nearest distance."""
+    fx = gu.load(name)
+    N = int(fx["meta_N"])
+    over = gu.config_overrides(fx)
+    env = uamenv.BatchedSingleAircraftEnv(1, N, variant="her3", rng="mt19937", precision="exact", seed=int(fx["meta_seed"]),
+                                          auto_reset=False, sparse_reward=over["sparse_reward"],
+                                          wall_terminates=over["wall_terminates"], knn=over["knn"])
+    assert env.cfg.shaped_reward == 1 and env.cfg.goal_margin == 100.0 and env.cfg.conflict_coeff == over["conflict_coeff"]
+    env.reset()                       # the reference's constructor resets once
+    tol = 1e-5
+    assert np.abs(env.reset().cpu().numpy()[0] - fx["obs0"]).max() <= tol
+    reset_steps = {int(t): i for i, t in enumerate(fx["reset_steps"])}
+    for t in range(len(fx["actions"])):
+        obs, rew, done, infos = env.step(fx["actions"][t:t + 1])
+        where = "%s step %d" % (name, t)
+        assert bool(done[0].item()) == bool(fx["done"][t]) and int(infos.codes[0].item()) == int(fx["info"][t]), where
+        assert abs(float(rew[0].item()) - fx["reward"][t]) <= tol, where
+        assert abs(float(env.nearest()[0].item()) - fx["nearest"][t]) <= tol * fx["nearest"][t], where + " nearest"
+        assert np.abs(obs.cpu().numpy()[0] - fx["obs"][t]).max() <= tol, where + " obs"
+        if fx["done"][t]:
+            assert np.abs(env.reset().cpu().numpy()[0] - fx["reset_obs"][reset_steps[t]]).max() <= tol, where + " reset obs"
+    env.close()
+
+
+def test_her3_gym_class(uamenv):
+    fx = gu.load("g14_her3_n8_seed51")
+    env = uamenv.SingleAircraftDiscrete3HEREnv(num_intruders=8)
+    env.seed(51)
+    ob = env.reset()
+    assert env.action_space.n == 3 and env.observation_space.shape == (26,)
+    flat = np.concatenate([ob["observation"], ob["achieved_goal"], ob["desired_goal"]])
+    assert np.abs(flat - fx["obs0"]).max() <= 1e-5
+    ob, r, d, near = env.step(int(fx["actions"][0]))
+    assert abs(r - fx["reward"][0]) <= 1e-5 and isinstance(near, float) and abs(near - fx["nearest"][0]) <= 1e-3
+    env.close()
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_her_relabel_matches_reference_and_oracle(uamenv, oracle, sparse):
+    """uam_her_goal_reward / uam_her_input_reward against the reference's own outputs (g15) and the oracle."""
+    import torch
+    fx = gu.load("g15_her_relabel")
+    X = torch.from_numpy(fx["inputs"]).cuda()
+    tag = "sparse" if sparse else "dense"
+    rew, done = uamenv.her_input_reward(X, sparse_reward=sparse, num_intruders=int(fx["meta_N"]), knn=int(fx["meta_knn"]))
+    want = fx["input_reward9_" + tag]
+    assert np.abs(rew.cpu().numpy() - want).max() <= 1e-6
+    assert np.array_equal(done.cpu().numpy(), (want == 1.0) | (want == -1.0))       # agent_her.py:117 (r_n == 10 or -10, scaled)
+    cat = lambda r: np.select([r == 1.0, r == -1.0, r == -0.5], [1, 2, 3], 0)
+    assert np.array_equal(cat(rew.cpu().numpy().astype(np.float64)), cat(want)), "reward categories must be exact"
+    g = uamenv.her_goal_reward(X[:, :2], X[:, -2:], sparse_reward=sparse)
+    assert np.abs(g.cpu().numpy() - fx["goal_reward9_" + tag]).max() <= 1e-6
+    # a larger random batch against the oracle (portable math = the device's x * x convention): bit-exact after the float32 cast
+    rs = np.random.RandomState(3)
+    big = rs.uniform(0, 1, size=(20000, 26)).astype(np.float32)
+    big[::3, 4:6] = big[::3, 0:2] + rs.uniform(-0.03, 0.03, size=(len(big[::3]), 2)).astype(np.float32)
+    big[1::3, -2:] = big[1::3, 0:2] + rs.uniform(-0.03, 0.03, size=(len(big[1::3]), 2)).astype(np.float32)
+    ocfg = oracle.default_config(1, 8, obs_mode=oracle.OBS_KNN5, knn=4, sparse_reward=int(sparse))
+    rew, _ = uamenv.her_input_reward(torch.from_numpy(big).cuda(), sparse_reward=sparse, num_intruders=8, knn=4)
+    want = oracle.her_input_reward(ocfg, big.astype(np.float64), oracle.MATH_PORTABLE).astype(np.float32)
+    assert np.array_equal(rew.cpu().numpy(), want)
+    assert len(set(np.round(want[want > -0.6], 3).tolist()) & {1.0, -0.5}) == 2 and (want == -1.0).any()
+    g = uamenv.her_goal_reward(torch.from_numpy(big[:, :2].copy()).cuda(), torch.from_numpy(big[:, -2:].copy()).cuda(), sparse_reward=sparse)
+    assert np.array_equal(g.cpu().numpy(), oracle.her_goal_reward(ocfg, big[:, :2], big[:, -2:]).astype(np.float32))

@@ -50,6 +50,9 @@ def test_oracle_replays_reference_bit_exact(oracle, name):
         assert info[0] == fx["info"][t], where + ": info"
         st = env.get_state()
         assert st["no_conflict"][0] == fx["no_conflict"][t], where + ": no_conflict"
+        if "nearest" in fx:      # Discrete3HEREnv.step's 4th return value
+            nd, nf = env.nearest()
+            assert nd[0] == fx["nearest"][t] and nf[0] == fx["nearest_f64"][t], where + ": nearest %r vs %r" % (nd[0], fx["nearest"][t])
         if done[0]:
             assert t in reset_steps
             ro = env.reset()
@@ -95,6 +98,21 @@ def test_oracle_shared_stream_matches_g10(oracle):
         assert np.array_equal(rew, fx["reward"][t])
         assert np.array_equal(done, fx["done"][t])
         assert np.array_equal(info, fx["info"][t])
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_oracle_her_relabel_matches_reference(oracle, sparse):
+    """compute_reward / compute_input_reward of both HER envs (g15), bit-exact float64."""
+    fx = gu.load("g15_her_relabel")
+    cfg = oracle.default_config(1, int(fx["meta_N"]), obs_mode=oracle.OBS_KNN5, knn=int(fx["meta_knn"]), sparse_reward=int(sparse))
+    X = fx["inputs"].astype(np.float64)
+    tag = "sparse" if sparse else "dense"
+    got = oracle.her_input_reward(cfg, X)
+    assert np.array_equal(got, fx["input_reward9_" + tag]) and np.array_equal(got, fx["input_reward3_" + tag])
+    got = oracle.her_goal_reward(cfg, X[:, :2], X[:, -2:])
+    assert np.array_equal(got, fx["goal_reward9_" + tag]) and np.array_equal(got, fx["goal_reward3_" + tag])
+    kinds = set(np.round(fx["input_reward9_sparse"], 6).tolist())
+    assert kinds == {-1.0, -0.5, -0.001, 1.0}, kinds     # NMAC, conflict, step, goal rows all present
 
 
 def test_numpy_legacy_rng_known_answers(oracle):
