@@ -107,6 +107,7 @@ struct UamParams {
     float inv_W32, inv_H32, inv_vden32;  /* reciprocals for the normalised float32 obs */
     float nmac_pen32, conf_pen32;
     float near_thr32, near_coeff32;      /* float32(3 * minimum_separation), float32(conflict_coeff) */
+    float inv_diag32;                    /* 1 / float32(Config.diagonal) */
     float spawn_sx, spawn_sy, min_speed32, vrange32;   /* float32 spawn (lean Philox mode) */
     const double2* noise;         /* [B] (zh, zs) of this step, produced ahead by uam_noise_kernel (Philox) */
     /* per-call I/O (device pointers owned by the caller) */
@@ -303,15 +304,69 @@ __device__ __forceinline__ void uam_philox_normals(uint32_t gid, uint32_t c_step
 template <bool POS64> struct PosT { typedef float type; };
 template <> struct PosT<true> { typedef double type; };
 
+/* Butterfly all-reduce inside an aligned group of L = 2^k lanes.  The first four levels are DPP lane
+ * permutations (no LDS round trip, unlike ds_bpermute): xor 1 and xor 2 as quad_perm, then
+ * row_half_mirror / row_mirror — lane i reads lane 7-i / 15-i, which is a valid partner because after the
+ * previous level every lane of the partner's sub-block already holds that sub-block's result.  Levels 16
+ * and 32 cross DPP rows and use ds_bpermute.  `op` must be associative and commutative. */
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) { return __uint_as_float(dpp_mov<CTRL>(__float_as_uint(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = dpp_mov<CTRL>((uint32_t)b), hi = dpp_mov<CTRL>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int o) { return (uint32_t)__shfl_xor((int)v, o); }
+__device__ __forceinline__ float lane_xor(float v, int o) { return __shfl_xor(v, o); }
+__device__ __forceinline__ double lane_xor(double v, int o) { return __shfl_xor(v, o); }
+
+#define UAM_DPP_QUAD_XOR1 0xB1      /* quad_perm:[1,0,3,2] */
+#define UAM_DPP_QUAD_XOR2 0x4E      /* quad_perm:[2,3,0,1] */
+#define UAM_DPP_HALF_MIRROR 0x141   /* row_half_mirror */
+#define UAM_DPP_ROW_MIRROR 0x140    /* row_mirror */
+
+/* one value */
+template <typename T, typename Op> __device__ __forceinline__ T grp_reduce(T v, int L, Op op)
+{
+    if (L >= 2) v = op(v, dpp_mov<UAM_DPP_QUAD_XOR1>(v));
+    if (L >= 4) v = op(v, dpp_mov<UAM_DPP_QUAD_XOR2>(v));
+    if (L >= 8) v = op(v, dpp_mov<UAM_DPP_HALF_MIRROR>(v));
+    if (L >= 16) v = op(v, dpp_mov<UAM_DPP_ROW_MIRROR>(v));
+    for (int o = 16; o < L; o <<= 1) v = op(v, lane_xor(v, o));
+    return v;
+}
+/* (key, index) pairs: op(a_key, a_idx, b_key, b_idx) -> true when b wins */
+template <typename T, typename Better>
+__device__ __forceinline__ void grp_reduce_pair(T& k, uint32_t& i, int L, Better better)
+{
+#define UAM_PAIR_STEP(K2, I2) { const T k2 = (K2); const uint32_t i2 = (I2); if (better(k, i, k2, i2)) { k = k2; i = i2; } }
+    if (L >= 2) UAM_PAIR_STEP(dpp_mov<UAM_DPP_QUAD_XOR1>(k), dpp_mov<UAM_DPP_QUAD_XOR1>(i))
+    if (L >= 4) UAM_PAIR_STEP(dpp_mov<UAM_DPP_QUAD_XOR2>(k), dpp_mov<UAM_DPP_QUAD_XOR2>(i))
+    if (L >= 8) UAM_PAIR_STEP(dpp_mov<UAM_DPP_HALF_MIRROR>(k), dpp_mov<UAM_DPP_HALF_MIRROR>(i))
+    if (L >= 16) UAM_PAIR_STEP(dpp_mov<UAM_DPP_ROW_MIRROR>(k), dpp_mov<UAM_DPP_ROW_MIRROR>(i))
+    for (int o = 16; o < L; o <<= 1) UAM_PAIR_STEP(lane_xor(k, o), lane_xor(i, o))
+#undef UAM_PAIR_STEP
+}
+
 __device__ __forceinline__ uint32_t grp_min(uint32_t v, int L)
 {
-    for (int o = L >> 1; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
-    return v;
+    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return min(a, b); });
+}
+__device__ __forceinline__ uint32_t grp_max(uint32_t v, int L)
+{
+    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return max(a, b); });
 }
 __device__ __forceinline__ uint32_t grp_add(uint32_t v, int L)
 {
-    for (int o = L >> 1; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
+    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return a + b; });
+}
+__device__ __forceinline__ uint32_t grp_or(uint32_t v, int L)
+{
+    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return a | b; });
 }
 
 /* np.linalg.norm(own - intruder) < thr, SingleAircraftEnv.py:312-313 + NEP-50 compare.
@@ -547,7 +602,7 @@ __device__ __forceinline__ void quad_obs(const UamParams& p, float* dst, bool ve
 __device__ __forceinline__ void obs_tail(const UamParams& p, float ox, float oy, double vx, double vy, double sp,
                                          double hd, double gx, double gy, float* t)
 {
-    if (p.obs_mode == UAM_OBS_NORM4) {
+    if (p.obs_mode == UAM_OBS_NORM4 || p.obs_mode == UAM_OBS_KNN5) {
         t[0] = ox * p.inv_W32;
         t[1] = oy * p.inv_H32;
         t[2] = (float)((vx + p.c->max_speed) * p.c->inv_2vmax);
@@ -573,6 +628,81 @@ __device__ __forceinline__ void store_tail(const UamParams& p, float* dst, bool 
     }
 }
 
+/* the wave streams its staged rows (LDS, final [env][D] layout) to HBM, 16 B per lane */
+__device__ __forceinline__ void obs_copy_out(const UamParams& p, const float* stage, int env_first, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int envs_per_wave = 64 >> p.lshift;
+    const int nrows = min(envs_per_wave, p.B - env_first);
+    const int chunks = nrows * (p.D >> 2);
+    float4* gdst = (float4*)(p.obs + (size_t)env_first * p.D);
+    /* non-temporal: the observation is written once and never read back by the env, so it must not
+     * evict the SoA state (re-read next step) from L2 / Infinity Cache: -8 % at 65536 envs, -16 % at 1 M */
+    typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
+    for (int c = lane; c < chunks; c += 64)
+        __builtin_nontemporal_store(((const uam_f32x4*)stage)[c], &((uam_f32x4*)gdst)[c]);
+}
+
+/* UAM_OBS_KNN5 row of one env, built by its lane group from the quads in registers:
+ * SingleAircraftDiscrete9HEREnv._get_ob (Discrete9HEREnv.py:105-165).  Every lane measures its quad, then
+ * `knn` rounds of an in-group (distance, index) min-reduction pick the nearest remaining intruder
+ * (ascending distance, ties to the lower index: np.argpartition + argsort) and the owner lane writes
+ * that neighbour's 5 values.  (ox, oy) = the ownship the distances refer to; t = normalised tail. */
+template <bool POS64, bool SH>
+__device__ __forceinline__ void knn_row(const UamParams& p, float* row, int gl, int L, bool env_ok, bool quad_ok,
+                                        const Quad<POS64, SH>& q, float ox, float oy, const float* t)
+{
+    typedef typename PosT<POS64>::type DT;      /* float32 distances unless positions can be promoted */
+    DT d[4];
+    uint32_t avail = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
+        if (POS64 && prom) {
+            const double dx = (double)ox - (double)q.x[j], dy = (double)oy - (double)q.y[j];
+            d[j] = (DT)__builtin_sqrt(uam_fma(dy, dy, dx * dx));
+        } else {
+            const float dx = ox - (float)q.x[j], dy = oy - (float)q.y[j];
+            d[j] = (DT)__builtin_sqrtf(dx * dx + dy * dy);
+        }
+        if (quad_ok && 4u * gl + j < (uint32_t)p.N) avail |= 1u << j;
+    }
+    for (int r = 0; r < p.knn; r++) {
+        DT bd = (DT)3.0e38f;
+        int bj = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (((avail >> j) & 1u) && d[j] < bd) { bd = d[j]; bj = j; }
+        const uint32_t bi = bj >= 0 ? 4u * gl + (uint32_t)bj : 0xFFFFu;
+        DT gd = bd;
+        uint32_t gi = bi;
+        grp_reduce_pair(gd, gi, L, [](DT a, uint32_t ai, DT b, uint32_t bi2) { return b < a || (b == a && bi2 < ai); });
+        if (gi == bi && bj >= 0) {                 /* this lane owns the r-th nearest intruder */
+            avail &= ~(1u << bj);
+            float* dst = row + 4 + 5 * r;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j == bj) {
+                    const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
+                    dst[0] = prom ? (float)((double)q.x[j] * p.c->inv_W) : (float)q.x[j] * p.inv_W32;
+                    dst[1] = prom ? (float)((double)q.y[j] * p.c->inv_H) : (float)q.y[j] * p.inv_H32;
+                    dst[2] = (q.vx[j] + p.vmax32) * p.inv_vden32;
+                    dst[3] = (q.vy[j] + p.vmax32) * p.inv_vden32;
+                    /* dist / Config.diagonal: float32 / int -> float32 quotient; float64 for a promoted intruder */
+                    dst[4] = prom ? (float)((double)bd * p.c->inv_diag) : (float)bd * p.inv_diag32;
+                }
+        }
+    }
+    if (env_ok && gl == 0) {
+        row[0] = t[0]; row[1] = t[1]; row[2] = t[2]; row[3] = t[3];
+        float* tl = row + 4 + 5 * p.knn;
+        tl[0] = t[0]; tl[1] = t[1];          /* achieved_goal */
+        tl[2] = t[6]; tl[3] = t[7];          /* desired_goal */
+    }
+}
+
 /* Observation pack of one wave.  Aligned case: every lane stages its piece of the rows in LDS in
  * the final [env][D] layout, then the wave streams its contiguous span of rows to HBM with 16 B
  * per lane (1 KiB per store instruction) — row-per-lane stores straight to HBM touch a different
@@ -587,23 +717,26 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, 
         float* row = stage + (size_t)g_in_wave * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, true, min(4, p.N - 4 * gl), q);
         if (env_ok) store_tail(p, row + (size_t)p.N * p.obs_w, true, gl, tail);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int envs_per_wave = 64 >> p.lshift;
-        const int nrows = min(envs_per_wave, p.B - env_first);
-        const int chunks = nrows * (p.D >> 2);
-        float4* gdst = (float4*)(p.obs + (size_t)env_first * p.D);
-        const float4* src = (const float4*)stage;
-        /* non-temporal: the observation is written once and never read back by the env, so it must not
-         * evict the SoA state (re-read next step) from L2 / Infinity Cache: -8 % at 65536 envs, -16 % at 1 M */
-        typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
-        for (int c = lane; c < chunks; c += 64)
-            __builtin_nontemporal_store(((const uam_f32x4*)src)[c], &((uam_f32x4*)gdst)[c]);
+        obs_copy_out(p, stage, env_first, lane);
     } else if (env_ok) {
         float* row = p.obs + (size_t)(env_first + g_in_wave) * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, false, min(4, p.N - 4 * gl), q);
         store_tail(p, row + (size_t)p.N * p.obs_w, false, gl, tail);
+    }
+}
+
+/* reset / observe kernels: either observation layout, chosen at run time */
+template <bool POS64, bool SH>
+__device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int env_first, int env, int g_in_wave, int gl,
+                                         bool env_ok, bool quad_ok, const Quad<POS64, SH>& q, float ox, float oy,
+                                         const float* tail)
+{
+    if (p.obs_mode == UAM_OBS_KNN5) {
+        float* row = p.obs_vec ? stage + (size_t)g_in_wave * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
+        knn_row<POS64, SH>(p, row, gl, p.L, env_ok, quad_ok, q, ox, oy, tail);
+        if (p.obs_vec) obs_copy_out(p, stage, env_first, threadIdx.x & 63);
+    } else {
+        obs_pack_wave<POS64, SH>(p, stage, env_first, g_in_wave, gl, env_ok, quad_ok, q, tail);
     }
 }
 
@@ -617,14 +750,27 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, 
  * ROS = SingleAircraftRandomEnv's random ownship start (needs fp64 trig here). */
 template <bool POS64, int RNG, bool SH, bool ROS>
 __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, Rng<RNG>& rng,
-                                 Quad<POS64, SH>& q, float* tail)
+                                 Quad<POS64, SH>& q, float* tail, float& rox, float& roy)
 {
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
     const uint32_t rc = p.s.reset_count[env];
     rng.c_reset = rc;
     double ox = p.c->own_x0, oy = p.c->own_y0, osp = p.c->own_speed0, ohd = p.c->own_heading0;
     double ovx = p.c->own_vx0, ovy = p.c->own_vy0;
-    if constexpr (ROS) {   /* SingleAircraftRandomEnv.py:70-74 */
+    if constexpr (ROS && LEAN) {
+        /* float32 Philox mode: like the lean intruder spawn, the random ownship start is float32 arithmetic on
+         * the Philox words (24-bit x, y, speed; heading = the top 26 bits as a fraction of a turn), so the
+         * sweep kernel carries no fp64 trig */
+        uint32_t w[4];
+        rng.block(true, UAM_PH_RESET_OWN, 0, 0, w);
+        const float fx = (float)(w[0] >> 8) * p.spawn_sx, fy = (float)(w[1] >> 8) * p.spawn_sy;
+        const float spf = p.min_speed32 + p.vrange32 * ((float)(w[2] >> 8) * 0x1p-24f);
+        float sn, cs;
+        uam_sincos_turn_f32(w[3], &sn, &cs);
+        ox = (double)fx; oy = (double)fy; osp = (double)spf;
+        ohd = (double)(w[3] >> 6) * (UAM_TWO_PI * 0x1p-26);
+        ovx = (double)(spf * cs); ovy = (double)(spf * sn);
+    } else if constexpr (ROS) {   /* SingleAircraftRandomEnv.py:70-74 */
         double u[4];
         rng.quad(true, UAM_PH_RESET_OWN, 0, u);
         ox = 0.0 + p.c->W * u[0]; oy = 0.0 + p.c->H * u[1];
@@ -667,6 +813,7 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
         p.s.reset_count[env] = rc + 1u;
     }
     obs_tail(p, oxf, oyf, ovx, ovy, osp, ohd, gx, gy, tail);
+    rox = oxf; roy = oyf;
 }
 
 /* ------------------------------------------------------------------ launch 1: ownship kernel
@@ -726,7 +873,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     const float rew = wall ? (float)c.wall_pen
                            : hit ? (float)c.goal_rew : (p.sparse_reward ? (float)c.step_pen : (float)(-dg / c.dense_div));
     float t[8];
-    if (p.obs_mode == UAM_OBS_NORM4) {
+    if (p.obs_mode == UAM_OBS_NORM4 || p.obs_mode == UAM_OBS_KNN5) {
         t[0] = ox * p.inv_W32;
         t[1] = oy * p.inv_H32;
         t[2] = (float)((vx + c.max_speed) * c.inv_2vmax);
@@ -763,12 +910,15 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
  * hand the 48-byte records over through LDS, and one block barrier later everyone sweeps.  Saves the
  * separate launch (5.5 us of pure latency at B=65536).  Used by every Philox configuration; the threads
  * that run the ownship phase fetch their quad after it, so the phase never adds register pressure. */
-/* DYN: 0 straight-line intruders, 1 RandIntruder, 2 straight-line + the reward shaped by the nearest swept intruder */
-template <bool POS64, int RNG, int DYN, bool SH, bool ROS, bool FUSED>
+/* MODE bits: 1 RandIntruder dynamics, 2 reward shaped by the nearest swept intruder, 4 k-nearest observation */
+#define UAM_MODE_RI 1
+#define UAM_MODE_SHAPED 2
+#define UAM_MODE_KNN 4
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     typedef typename PosT<POS64>::type P;
-    constexpr bool RI = DYN == 1, SHAPED = DYN == 2;
+    constexpr bool RI = (MODE & UAM_MODE_RI) != 0, SHAPED = (MODE & UAM_MODE_SHAPED) != 0, KNN = (MODE & UAM_MODE_KNN) != 0;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
@@ -926,21 +1076,17 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     else if (tail_code) { reward = s0.z; done = true; info = tail_code == 2u ? UAM_INFO_WALL : UAM_INFO_GOAL; }
     else { reward = s0.z; done = false; info = UAM_INFO_NONE; }
     if constexpr (SHAPED && !POS64) {
-        uint32_t any = near_tag;
-        for (int o = L >> 1; o > 0; o >>= 1) {
-            near_d2 = fminf(near_d2, __shfl_xor(near_d2, o));
-            any |= (uint32_t)__shfl_xor((int)any, o);
-        }
+        const uint32_t any = grp_or(near_tag, L);
+        near_d2 = grp_reduce(near_d2, L, [](float a, float b) { return fminf(a, b); });
         const float nf = any ? __builtin_sqrtf(near_d2) : 9999.0f;
         /* :225-232: float32 distance -> float32 arithmetic (NEP 50) */
         if (info == UAM_INFO_NONE && any && nf < p.near_thr32) reward = reward + (p.near_coeff32 * nf - 0.1f);
         if (env_ok && gl == 0) p.s.nearest[env] = nf;
     }
     if constexpr (SHAPED && POS64) {
-        double gmin = near_d;
-        for (int o = L >> 1; o > 0; o >>= 1) gmin = fmin(gmin, __shfl_xor(gmin, o));
-        uint32_t tag = near_d == gmin ? near_tag : 0u;       /* ties across lanes: the later intruder, as in the loop */
-        for (int o = L >> 1; o > 0; o >>= 1) tag = max(tag, (uint32_t)__shfl_xor((int)tag, o));
+        const double gmin = grp_reduce(near_d, L, [](double a, double b) { return fmin(a, b); });
+        /* ties across lanes: the later intruder, as in the loop */
+        const uint32_t tag = grp_max(near_d == gmin ? near_tag : 0u, L);
         if (info == UAM_INFO_NONE && tag) {   /* :225-232, NEP-50 arithmetic on the distance's dtype */
             if (tag & 1u) {
                 const double r = gmin < pk.c->near_thr ? pk.c->near_coeff * gmin - 0.1 : 0.0;
@@ -1022,16 +1168,17 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     float tail[8];
     {
         const float4 t0 = (gl == 0) ? shp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 t1 = (gl == second || !p.obs_vec) ? shp[2] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t1 = (gl == second || !p.obs_vec || KNN) ? shp[2] : make_float4(0.f, 0.f, 0.f, 0.f);
         tail[0] = t0.x; tail[1] = t0.y; tail[2] = t0.z; tail[3] = t0.w;
         tail[4] = t1.x; tail[5] = t1.y; tail[6] = t1.z; tail[7] = t1.w;
     }
 
     /* ---- VecEnv auto-reset: the obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
+    float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
         rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
-        reset_env<POS64, RNG, SH, ROS>(pk, env, gl, quad_ok, rng, q, tail);
+        reset_env<POS64, RNG, SH, ROS>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true;
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
@@ -1044,7 +1191,13 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     }
     if (p.obs && !(UAM_ABLATE & 2)) {
         float* stage = (float*)(lds_raw + (FUSED ? (size_t)p.E * 48 : 0)) + (size_t)wave_first_g * p.D;
-        obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+        if constexpr (KNN) {
+            float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
+            knn_row<POS64, SH>(p, row, gl, L, env_ok, quad_ok, q, kx, ky, tail);
+            if (p.obs_vec) obs_copy_out(p, stage, env_first, tid & 63);
+        } else {
+            obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+        }
     }
 }
 
@@ -1066,11 +1219,12 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParam
     Quad<POS64, SH> q;
     quad_load<POS64, SH>(p, base, quad_ok && !sel, q);   /* un-masked envs keep (and re-emit) their state */
     float tail[8];
+    float kx = 0.f, ky = 0.f;
     if (sel) {
         Rng<RNG> rng;
         rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         rng.load(p.s, env);
-        reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail);
+        reset_env<POS64, RNG, SH, ROS>(p, env, gl, quad_ok, rng, q, tail, kx, ky);
         if (gl == 0) rng.store(p.s, env);
         if (gl == 0 && p.track_ep) { p.s.ep_ret[env] = 0.0; p.s.ep_len[env] = 0; }   /* Monitor.reset */
         if (quad_ok) {
@@ -1079,12 +1233,13 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_reset_kernel(const UamParam
             p.s.qf[base >> 2] = (uint8_t)q.flags;
         }
     } else if (env_ok) {
-        obs_tail(p, p.s.own_x[env], p.s.own_y[env], p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
+        kx = p.s.own_x[env]; ky = p.s.own_y[env];
+        obs_tail(p, kx, ky, p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
                  p.s.goal_x[env], p.s.goal_y[env], tail);
     }
     if (p.obs) {
         float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
-        obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+        obs_emit<POS64, SH>(p, stage, env_first, env, g - wave_first_g, gl, env_ok, quad_ok, q, kx, ky, tail);
     }
 }
 
@@ -1105,87 +1260,14 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_observe_kernel(const UamPar
     Quad<POS64, SH> q;
     quad_load<POS64, SH>(p, base, quad_ok, q);
     float tail[8];
-    if (env_ok)
-        obs_tail(p, p.s.own_x[env], p.s.own_y[env], p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
+    float kx = 0.f, ky = 0.f;
+    if (env_ok) {
+        kx = p.s.own_x[env]; ky = p.s.own_y[env];
+        obs_tail(p, kx, ky, p.s.own_vx[env], p.s.own_vy[env], p.s.own_s[env], p.s.own_h[env],
                  p.s.goal_x[env], p.s.goal_y[env], tail);
+    }
     float* stage = (float*)lds_raw + (size_t)wave_first_g * p.D;
-    obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
-}
-
-/* UAM_OBS_KNN5: SingleAircraftDiscrete9HEREnv._get_ob (Discrete9HEREnv.py:105-165) from the CURRENT state,
- * one lane group per env: every lane computes the distances of its quad, then `knn` rounds of an in-group
- * (distance, index) min-reduction pick the nearest remaining intruder (ascending distance, ties to the
- * lower index — np.argpartition + argsort); the owner lane writes that neighbour's 5 values.  Runs as its
- * own launch after the sweep (which is then told to skip the obs): the rows are 4 + 5 knn + 4 floats. */
-template <bool POS64>
-__global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_knn_obs_kernel(const UamParams p)
-{
-    const int tid = threadIdx.x;
-    const int L = p.L;
-    const int g = tid >> p.lshift, gl = tid & (L - 1);
-    const int env = blockIdx.x * p.E + g;
-    if (env >= p.B) return;                       /* whole lane group: shuffles stay inside the group */
-    const bool quad_ok = gl < p.Q;
-    const size_t base = (size_t)env * p.Np + 4u * gl;
-    Quad<POS64, false> q;
-    quad_load<POS64, false>(p, base, quad_ok, q);
-    const float ox = p.s.own_x[env], oy = p.s.own_y[env];
-    double d[4];
-    uint32_t avail = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
-        if (POS64 && prom) {
-            const double dx = (double)ox - (double)q.x[j], dy = (double)oy - (double)q.y[j];
-            d[j] = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
-        } else {
-            const float dx = ox - (float)q.x[j], dy = oy - (float)q.y[j];
-            d[j] = (double)__builtin_sqrtf(dx * dx + dy * dy);
-        }
-        if (quad_ok && 4u * gl + j < (uint32_t)p.N) avail |= 1u << j;
-    }
-    float* row = p.obs + (size_t)env * p.D;
-    for (int r = 0; r < p.knn; r++) {
-        double bd = 1.0e300;
-        int bj = -1;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (((avail >> j) & 1u) && d[j] < bd) { bd = d[j]; bj = j; }
-        uint32_t bi = bj >= 0 ? 4u * gl + (uint32_t)bj : 0xFFFFu;
-        double gd = bd;
-        uint32_t gi = bi;
-        for (int o = L >> 1; o > 0; o >>= 1) {
-            const double d2 = __shfl_xor(gd, o);
-            const uint32_t i2 = (uint32_t)__shfl_xor((int)gi, o);
-            if (d2 < gd || (d2 == gd && i2 < gi)) { gd = d2; gi = i2; }
-        }
-        if (gi == bi && bj >= 0) {                 /* this lane owns the r-th nearest intruder */
-            avail &= ~(1u << bj);
-            float* dst = row + 4 + 5 * r;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (j == bj) {
-                    const bool prom = POS64 && ((q.flags >> (4 + j)) & 1u);
-                    dst[0] = prom ? (float)((double)q.x[j] * p.c->inv_W) : (float)q.x[j] * p.inv_W32;
-                    dst[1] = prom ? (float)((double)q.y[j] * p.c->inv_H) : (float)q.y[j] * p.inv_H32;
-                    dst[2] = (q.vx[j] + p.vmax32) * p.inv_vden32;
-                    dst[3] = (q.vy[j] + p.vmax32) * p.inv_vden32;
-                    dst[4] = (float)(bd * p.c->inv_diag);
-                }
-        }
-    }
-    if (gl == 0) {
-        const double ovx = p.s.own_vx[env], ovy = p.s.own_vy[env];
-        row[0] = ox * p.inv_W32;
-        row[1] = oy * p.inv_H32;
-        row[2] = (float)((ovx + p.c->max_speed) * p.c->inv_2vmax);
-        row[3] = (float)((ovy + p.c->max_speed) * p.c->inv_2vmax);
-        float* tl = row + 4 + 5 * p.knn;
-        tl[0] = ox * p.inv_W32;                                  /* achieved_goal */
-        tl[1] = oy * p.inv_H32;
-        tl[2] = (float)(p.s.goal_x[env] * p.c->inv_W);           /* desired_goal */
-        tl[3] = (float)(p.s.goal_y[env] * p.c->inv_H);
-    }
+    obs_emit<POS64, SH>(p, stage, env_first, env, g - wave_first_g, gl, env_ok, quad_ok, q, kx, ky, tail);
 }
 
 /* ownship noise drawn ahead for K consecutive steps (Philox): out[k*B + e] = (zh, zs) of step base+k.

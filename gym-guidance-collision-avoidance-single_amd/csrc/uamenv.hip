@@ -214,6 +214,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->knn = c.knn;
     p->shaped = c.shaped_reward ? 1 : 0;
     p->near_thr32 = (float)(3 * c.minimum_separation); p->near_coeff32 = (float)c.conflict_coeff;
+    p->inv_diag32 = c.diagonal > 0 ? 1.0f / (float)c.diagonal : 0.f;
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
@@ -281,7 +282,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
     /* Philox configurations run the ownship phase inside the sweep launch (one launch per step); the
      * MT19937 stream and the random-ownship-start variant keep the separate ownship kernel */
-    e->fused = cfg->rng_mode == UAM_RNG_PHILOX && !cfg->random_own_start;
+    e->fused = cfg->rng_mode == UAM_RNG_PHILOX;
     if (const char* fz = getenv("UAMENV_FUSED")) e->fused = e->fused && atoi(fz) != 0;   /* development override */
 
     const size_t BI = (size_t)B * e->Np;
@@ -409,7 +410,10 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
     const size_t lds = lds_stage(e, p);
     if constexpr (RNG == UAM_RNG_PHILOX) {
         if (e->fused) {   /* ownship phase inside the sweep launch */
-            hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p);
+            if (e->cfg.random_own_start)
+                hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, true>), grid, block, lds + (size_t)e->E * 48, st, p);
+            else
+                hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p);
             return;
         }
     }
@@ -422,10 +426,13 @@ static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t s
 template <bool POS64, int RNG>
 static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
 {
-    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, 1, true>(e, p, st);
+    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;       /* never with held speed/heading (validate) */
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, UAM_MODE_RI, true>(e, p, st);
+    else if (knn && e->cfg.shaped_reward) launch_sweep_ros<POS64, RNG, UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e, p, st);
+    else if (knn) launch_sweep_ros<POS64, RNG, UAM_MODE_KNN, false>(e, p, st);
     else if (e->cfg.shaped_reward) {
-        if (e->hold_sh) launch_sweep_ros<POS64, RNG, 2, true>(e, p, st);
-        else launch_sweep_ros<POS64, RNG, 2, false>(e, p, st);
+        if (e->hold_sh) launch_sweep_ros<POS64, RNG, UAM_MODE_SHAPED, true>(e, p, st);
+        else launch_sweep_ros<POS64, RNG, UAM_MODE_SHAPED, false>(e, p, st);
     }
     else if (e->hold_sh) launch_sweep_ros<POS64, RNG, 0, true>(e, p, st);
     else launch_sweep_ros<POS64, RNG, 0, false>(e, p, st);
@@ -471,14 +478,6 @@ static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
     else { if (sh) launch_reset_ros<false, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_PHILOX, false>(e, p, st); }
 }
 
-/* UAM_OBS_KNN5 rows are produced by their own launch from the committed state */
-static void launch_knn_obs(const uam_env* e, const UamParams& p, hipStream_t st)
-{
-    dim3 grid(grid_of(e)), block(e->T);
-    if (e->cfg.precision == UAM_POS_EXACT) hipLaunchKernelGGL((uam_knn_obs_kernel<true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((uam_knn_obs_kernel<false>), grid, block, 0, st, p);
-}
-
 static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)
 {
     if (obs && ((uintptr_t)obs & 3u)) return fail(UAM_EINVAL, "obs_out must be 4-byte aligned");
@@ -495,10 +494,8 @@ extern "C" int uam_reset(uam_env* e, const uint8_t* mask_dev, float* obs_out, vo
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.mask = mask_dev;
-    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
-    p.obs = knn ? nullptr : obs_out;
+    p.obs = obs_out;
     launch_reset(e, p, (hipStream_t)stream);
-    if (knn && obs_out) { p.obs = obs_out; launch_knn_obs(e, p, (hipStream_t)stream); }
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
@@ -524,10 +521,7 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
         }
         p.noise = e->noise + (size_t)(e->step_index - e->noise_base) * e->cfg.num_envs;
     }
-    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
-    if (knn) p.obs = nullptr;
     launch_step(e, p, st);
-    if (knn && obs_out) { p.obs = obs_out; launch_knn_obs(e, p, st); }
     HIP_TRY(hipGetLastError());
     e->step_index++;
     if (e->timing) e->timed_launches++;
@@ -582,11 +576,6 @@ extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.obs = obs_out;
-    if (e->cfg.obs_mode == UAM_OBS_KNN5) {
-        launch_knn_obs(e, p, (hipStream_t)stream);
-        HIP_TRY(hipGetLastError());
-        return UAM_OK;
-    }
     dim3 grid(grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
     const bool x = e->cfg.precision == UAM_POS_EXACT;
@@ -697,11 +686,14 @@ extern "C" int64_t uam_step_bytes(const uam_env* e)
 {
     if (!e) return 0;
     const int64_t posb = e->cfg.precision == UAM_POS_EXACT ? 8 : 4;
-    const int64_t obs_w = e->cfg.obs_mode == UAM_OBS_RAW6 ? 6 : (e->cfg.obs_mode == UAM_OBS_KNN5 ? 2 : 4);   /* KNN5: x,y re-read */
+    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
+    const int64_t obs_w = e->cfg.obs_mode == UAM_OBS_RAW6 ? 6 : (knn ? 0 : 4);
     /* per intruder: x,y read + write, vx,vy read, obs write (+ speed,heading read when held);
-     * per env: SURVEY §8d's 150 B (ownship, goal, flags, counters, action, obs tail, reward/done/info) */
+     * per env: SURVEY §8d's 150 B (ownship, goal, flags, counters, action, obs tail, reward/done/info);
+     * KNN5: no per-intruder obs, the row's 5*knn + 4 - 8 extra floats per env instead */
     const int64_t per_int = 4 * posb + 8 + 4 * obs_w + (e->hold_sh ? 16 : 0);
-    return (int64_t)e->cfg.num_envs * (per_int * e->cfg.num_intruders + 150);
+    const int64_t per_env = 150 + (knn ? 4 * (5 * (int64_t)e->cfg.knn - 4) : 0);
+    return (int64_t)e->cfg.num_envs * (per_int * e->cfg.num_intruders + per_env);
 }
 
 extern "C" int uam_kernel_timing(uam_env* e, int32_t enable)

@@ -309,7 +309,25 @@ static void env_reset(const ctx_t* c)
     env_t* e = c->e;
     double sn, cs;
     double ox = g->own_x0, oy = g->own_y0, osp = g->own_speed0, ohd = g->own_heading0;
-    if (g->random_own_start) {   /* SingleAircraftRandomEnv.py:70-74 */
+    const int hold_sh = g->dynamics == UAM_DYN_RANDINTRUDER || g->obs_mode == UAM_OBS_RAW6;
+    int lean_own = 0;
+    if (g->random_own_start && g->rng_mode == UAM_RNG_PHILOX && g->precision == UAM_POS_F32 && !hold_sh) {
+        /* "lean" float32 Philox mode (see spawn_intruder): 24-bit x, y, speed; heading = top 26 bits of a turn */
+        uint32_t w[4];
+        float sn32, cs32;
+        philox(c, PH_RESET_OWN, 0, 0, w);
+        const float sx = (float)g->window_width * 0x1p-24f, sy = (float)g->window_height * 0x1p-24f;
+        const float u = (float)(w[2] >> 8) * 0x1p-24f;
+        const float prod = (float)((float)(g->max_speed - g->min_speed) * u);
+        const float spf = (float)((float)g->min_speed + prod);
+        uam_sincos_turn_f32(w[3], &sn32, &cs32);
+        ox = (double)((float)(w[0] >> 8) * sx); oy = (double)((float)(w[1] >> 8) * sy);
+        osp = (double)spf;
+        ohd = (double)(w[3] >> 6) * (2.0 * M_PI * 0x1p-26);
+        e->own_vx = (double)(float)(spf * cs32);
+        e->own_vy = (double)(float)(spf * sn32);
+        lean_own = 1;
+    } else if (g->random_own_start) {   /* SingleAircraftRandomEnv.py:70-74 */
         if (g->rng_mode == UAM_RNG_MT19937) {
             ox = 0.0 + g->window_width * mt_double(e->mt);
             oy = 0.0 + g->window_height * mt_double(e->mt);
@@ -328,9 +346,11 @@ static void env_reset(const ctx_t* c)
     e->own_y = (float)oy;
     e->own_speed = osp;
     e->own_heading = ohd;
-    m_sincos(c->b, ohd, &sn, &cs);
-    e->own_vx = (double)(float)(osp * cs);   /* float32 velocity array of Aircraft.__init__ */
-    e->own_vy = (double)(float)(osp * sn);
+    if (!lean_own) {
+        m_sincos(c->b, ohd, &sn, &cs);
+        e->own_vx = (double)(float)(osp * cs);   /* float32 velocity array of Aircraft.__init__ */
+        e->own_vy = (double)(float)(osp * sn);
+    }
     e->own_v_f32 = 1;
     for (int i = 0; i < c->b->N; i++) spawn_intruder(c, i, 1, &e->in[i]);
     if (g->rng_mode == UAM_RNG_MT19937) {    /* Goal(position=self.random_pos()), :91 */
