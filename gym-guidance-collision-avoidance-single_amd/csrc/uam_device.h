@@ -1336,11 +1336,29 @@ __global__ void __launch_bounds__(256) uam_her_goal_reward_kernel(const UamHerPa
     p.reward[i] = d < p.goal_r ? (float)p.goal_rew : (p.sparse ? (float)p.step_pen : (float)(-d / p.dense_div));
 }
 
+/* STAGED: the block's 256 rows are fetched with 16-byte coalesced loads into LDS first (a row is D floats,
+ * e.g. 104 B: row-per-thread global loads would issue D strided 4-byte loads per lane) */
+template <bool STAGED>
 __global__ void __launch_bounds__(256) uam_her_input_reward_kernel(const UamHerParams p)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float her_lds[];
+    const long long row0 = (long long)blockIdx.x * 256;
+    const long long i = row0 + threadIdx.x;
+    const float* x;
+    if constexpr (STAGED) {
+        const long long nrows = p.M - row0 < 256 ? p.M - row0 : 256;
+        const int total = (int)nrows * p.D;
+        const float* src = p.a + row0 * p.D;           /* 16-byte aligned: base is, and 256 * D * 4 is a multiple of 16 */
+        typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
+        for (int c = threadIdx.x; c < (total >> 2); c += 256)
+            ((uam_f32x4*)her_lds)[c] = __builtin_nontemporal_load(&((const uam_f32x4*)src)[c]);
+        for (int c = (total & ~3) + threadIdx.x; c < total; c += 256) her_lds[c] = src[c];
+        __syncthreads();
+        x = her_lds + threadIdx.x * p.D;
+    } else {
+        x = p.a + i * p.D;
+    }
     if (i >= p.M) return;
-    const float* x = p.a + i * p.D;
     const double ownx = (double)x[0] * p.W, owny = (double)x[1] * p.H;
     const double gx = (double)x[p.D - 2] * p.W, gy = (double)x[p.D - 1] * p.H;
     double dx = ownx - gx, dy = owny - gy;

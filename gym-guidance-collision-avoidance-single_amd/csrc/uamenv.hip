@@ -640,7 +640,11 @@ extern "C" int uam_her_input_reward(const uam_config* cfg, int device, const flo
     if (M == 0) return UAM_OK;
     HIP_TRY(hipSetDevice(device));
     p.M = M; p.D = D; p.a = inputs_dev; p.reward = reward_out_dev; p.done = done_out_dev;
-    hipLaunchKernelGGL(uam_her_input_reward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    const size_t lds = (size_t)256 * D * 4;
+    if (lds <= 40 * 1024 && ((uintptr_t)inputs_dev & 15u) == 0)
+        hipLaunchKernelGGL(uam_her_input_reward_kernel<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(uam_her_input_reward_kernel<false>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }

@@ -453,6 +453,27 @@ def g10_shared_stream(Config, m_env):
          dict(obs0=obs0, obs_after=obs, reward=rew, done=done, info=info, no_conflict=nc, actions=acts))
 
 
+def g6_randomenv(Config, N, seed, T):
+    """G6b: SingleAircraftRandomEnv (random ownship start), goal-seeking policy."""
+    import SingleAircraftRandomEnv as m_rand
+    Config.intruder_size = N
+    np.random.seed(seed)
+    env = m_rand.SingleAircraftRandomEnv()
+    obs0 = env.reset()
+    st0 = snapshot(env)
+
+    def act(t, e):
+        a0, a1 = goal_seeking_action(e, Config.d_heading)
+        return a0 * 3 + a1
+
+    data = run_episode_stream(env, act, T, 25)
+    data["obs0"] = np.asarray(obs0)
+    add_prefixed(data, "st0_", st0)
+    data["actions"] = data["actions"].astype(np.int32)
+    save("g6_randomenv_n%d_seed%d" % (N, seed), dict(seed=seed, N=N, variant="SingleAircraftRandomEnv", obs_mode=0,
+                                                     action_mode=0, dynamics=0, random_own_start=1), data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -475,6 +496,7 @@ def main():
     g9_randintruder(Config, m_ri, 64, 14, 500)
     g9b_mctsenv(Config, m_mcts)
     g10_shared_stream(Config, m_env)
+    g6_randomenv(Config, 8, 31, 2000)
 
 
 if __name__ == "__main__":

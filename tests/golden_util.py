@@ -10,7 +10,7 @@ TRAJECTORY_FIXTURES = [
     "g1_discrete9_n4_seed0", "g2_goalseek_n8_seed3", "g2_goalseek_n32_seed1", "g2_goalseek_n80_seed4",
     "g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal",
     "g8_continuous_n8_seed7", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
-    "g9b_mctsenv_n8_seed11",
+    "g9b_mctsenv_n8_seed11", "g6_randomenv_n8_seed31",
 ]
 
 # SingleAircraftDiscrete9HEREnv (k-nearest observation, random ownship start, optional wall termination);
@@ -37,6 +37,8 @@ def config_overrides(fx, **extra):
     for k in ("heading_sigma", "speed_sigma"):
         if "meta_" + k in fx:
             over[k] = float(fx["meta_" + k])
+    if "meta_random_own_start" in fx:
+        over["random_own_start"] = int(fx["meta_random_own_start"])
     if int(fx["meta_obs_mode"]) == 3:   # HER family
         sparse = int(fx["meta_sparse_reward"])
         over.update(knn=int(fx["meta_knn"]), random_own_start=1, sparse_reward=sparse, wall_terminates=sparse)

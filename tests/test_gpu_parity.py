@@ -88,6 +88,8 @@ def test_gpu_replays_reference_fixture_from_seed(uamenv, name):
     fx = gu.load(name)
     N = int(fx["meta_N"])
     variant = VARIANT_OF[(int(fx["meta_obs_mode"]), int(fx["meta_action_mode"]), int(fx["meta_dynamics"]))]
+    if int(fx.get("meta_random_own_start", 0)):
+        variant = "random_start"          # Simulators/SingleAircraftRandomEnv.py
     over = {k: float(fx["meta_" + k]) for k in ("heading_sigma", "speed_sigma") if "meta_" + k in fx}
     env = uamenv.BatchedSingleAircraftEnv(1, N, variant=variant, rng="mt19937", precision="exact",
                                           seed=int(fx["meta_seed"]), auto_reset=False, **over)
@@ -504,5 +506,9 @@ def test_her_relabel_matches_reference_and_oracle(uamenv, oracle, sparse):
     want = oracle.her_input_reward(ocfg, big.astype(np.float64), oracle.MATH_PORTABLE).astype(np.float32)
     assert np.array_equal(rew.cpu().numpy(), want)
     assert len(set(np.round(want[want > -0.6], 3).tolist()) & {1.0, -0.5}) == 2 and (want == -1.0).any()
+    flat = torch.empty(big.size + 1, dtype=torch.float32, device="cuda")       # 4-byte-aligned rows: the un-staged kernel
+    flat[1:] = torch.from_numpy(big).cuda().reshape(-1)
+    rew2, _ = uamenv.her_input_reward(flat[1:].view(big.shape), sparse_reward=sparse, num_intruders=8, knn=4)
+    assert np.array_equal(rew2.cpu().numpy(), want)
     g = uamenv.her_goal_reward(torch.from_numpy(big[:, :2].copy()).cuda(), torch.from_numpy(big[:, -2:].copy()).cuda(), sparse_reward=sparse)
     assert np.array_equal(g.cpu().numpy(), oracle.her_goal_reward(ocfg, big[:, :2], big[:, -2:]).astype(np.float32))
