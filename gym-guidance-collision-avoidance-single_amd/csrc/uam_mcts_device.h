@@ -6,6 +6,8 @@
  *   SingleAircraftNode.expand / rollout / backpropagate     Algorithms/MCTS/nodes_single_randintru.py:202-224
  *   MCTSNode.best_child / rollout_policy                    Algorithms/MCTS/common.py:47-55
  *   MCTS.best_action / tree_policy                          Algorithms/MCTS/search_single.py:8-22
+ * and, as template parameter MODEL = UAM_MCTS_MODEL_STRAIGHT4, the 4-wide SingleAircraftState of
+ * Algorithms/MCTS/nodes_single.py:39-100 (Agent.py's planner) with its two upstream quirks.
  *
  * Execution shape: ONE WAVEFRONT PER ROOT.  UCT is sequential in its simulations, so the parallelism is
  * (a) across roots and (b) across the intruders inside every simulated frame of move(): lane l holds
@@ -39,6 +41,7 @@ enum { UAM_MPH_HEADCHG = 1, UAM_MPH_OWN_H = 2, UAM_MPH_POS = 3, UAM_MPH_ACTION =
 
 struct UamMctsParams {
     int B, N, K, Npad, cap, sims, depth, frames;
+    int Nsim, width;                     /* intruders the model moves and checks (N, or N - 1 for STRAIGHT4); root row stride */
     uint32_t seed_lo, seed_hi, root_id0;
     uint32_t sim_index, move_index;      /* uam_mcts_move only */
     double W, H, sep2, min_speed, max_speed, d_speed, speed_sigma, position_sigma, d_heading, heading_sigma,
@@ -97,10 +100,11 @@ __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepai
  * sincos of every frame's heading (lane f = frame f) are evaluated ONCE in parallel instead of once per
  * frame wave-uniformly.  The recurrences themselves (speed clamp, heading, position sums) run in the
  * reference's order, sequentially, so every rounding is the reference's.  Needs frames <= 64. */
-template <int K>
+template <int K, int MODEL>
 __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
                                      const double gx, const double gy, const int a0, const int a1, MctsState<K>& s)
 {
+    constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
     const int F = p.frames;
     const double d_heading = (double)(a0 - 1) * p.d_heading;
     const double accel = (double)(a1 - 1) * p.d_speed;
@@ -113,27 +117,51 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
     const int src = lane >> 1;
     const double zha = __shfl(zhp0, src), zhb = __shfl(zhp1, src), zsa = __shfl(zsp0, src), zsb = __shfl(zsp1, src);
     const double zh = (lane & 1) ? zhb : zha, zs = (lane & 1) ? zsb : zsa;      /* lane f holds frame f's noise */
-    /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
-    double spd = s.osp, hdg = s.ohd, my_sp = 0.0, my_hd = 0.0;
-    for (int f = 0; f < F; f++) {
-        const double zsf = __shfl(zs, f), zhf = __shfl(zh, f);
-        spd += accel;
-        spd = fmax(p.min_speed, fmin(spd, p.max_speed));
-        spd += 0.0 + p.speed_sigma * zsf;
-        hdg += d_heading;
-        hdg += 0.0 + p.heading_sigma * zhf;
-        if (lane == f) { my_sp = spd; my_hd = hdg; }
-    }
-    /* ---- every frame's velocity at once, :81-82 */
-    double sn, cs;
-    uam_sincos_k(my_hd, &sn, &cs);
-    const double my_vx = my_sp * cs, my_vy = my_sp * sn;
-    /* ---- positions in frame order, :83-86 */
-    double ox = s.ox, oy = s.oy, my_ox = 0.0, my_oy = 0.0;
-    for (int f = 0; f < F; f++) {
-        ox += __shfl(my_vx, f);
-        oy += __shfl(my_vy, f);
-        if (lane == f) { my_ox = ox; my_oy = oy; }
+    double my_sp = 0.0, my_hd = 0.0, my_vx = 0.0, my_vy = 0.0, my_ox = 0.0, my_oy = 0.0;
+    if constexpr (!M4) {
+        /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
+        double spd = s.osp, hdg = s.ohd;
+        for (int f = 0; f < F; f++) {
+            const double zsf = __shfl(zs, f), zhf = __shfl(zh, f);
+            spd += accel;
+            spd = fmax(p.min_speed, fmin(spd, p.max_speed));
+            spd += 0.0 + p.speed_sigma * zsf;
+            hdg += d_heading;
+            hdg += 0.0 + p.heading_sigma * zhf;
+            if (lane == f) { my_sp = spd; my_hd = hdg; }
+        }
+        /* ---- every frame's velocity at once, :81-82 */
+        double sn, cs;
+        uam_sincos_k(my_hd, &sn, &cs);
+        my_vx = my_sp * cs; my_vy = my_sp * sn;
+        /* ---- positions in frame order, :83-86 */
+        double ox = s.ox, oy = s.oy;
+        for (int f = 0; f < F; f++) {
+            ox += __shfl(my_vx, f);
+            oy += __shfl(my_vy, f);
+            if (lane == f) { my_ox = ox; my_oy = oy; }
+        }
+    } else {
+        /* nodes_single.py:59-71: the heading recurrence is independent of the speed, so every frame's heading
+         * and its sincos come first (lane f = frame f); the speed is then re-derived each frame from the
+         * previous frame's vy (state[-5], :60 — `accel` is dead), which chains through sin(heading) */
+        (void)accel;
+        double hdg = s.ohd;
+        for (int f = 0; f < F; f++) {
+            hdg += d_heading;
+            hdg += 0.0 + p.heading_sigma * __shfl(zh, f);
+            if (lane == f) my_hd = hdg;
+        }
+        double sn, cs;
+        uam_sincos_k(my_hd, &sn, &cs);
+        double vyp = s.ovy, ox = s.ox, oy = s.oy;
+        for (int f = 0; f < F; f++) {
+            double spd = fmax(p.min_speed, fmin(vyp, p.max_speed));
+            spd += 0.0 + p.speed_sigma * __shfl(zs, f);
+            const double vx = spd * __shfl(cs, f), vy = spd * __shfl(sn, f);
+            ox += vx; oy += vy; vyp = vy;
+            if (lane == f) { my_sp = spd; my_vx = vx; my_vy = vy; my_ox = ox; my_oy = oy; }
+        }
     }
     const bool in_f = lane < F;
     const bool wall = !(0.0 < my_ox && my_ox < p.W) || !(0.0 < my_oy && my_oy < p.H);
@@ -143,7 +171,8 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
 
     uint32_t flags = 0;
     int fe = F - 1;
-    uint32_t hw[K][4];
+    uint32_t hw[M4 ? 1 : K][4];
+    (void)hw; (void)sp;
     for (int f = 0; f < F; f++) {
         const uint32_t fp = (uint32_t)f >> 1;
         const int odd = f & 1;
@@ -151,7 +180,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int i = lane + 64 * k;
-            if (i < p.N) {
+            if (i < p.Nsim) {
                 double nx_ = 0.0, ny_ = 0.0;
                 if (p.position_sigma != 0.0) {
                     double z0, z1;
@@ -161,16 +190,18 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                 }
                 s.x[k] += s.vx[k] + nx_;
                 s.y[k] += s.vy[k] + ny_;
-                if (!odd) mcts_philox(rng, fp, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
-                const double pr = uam_u32d(odd ? hw[k][2] : hw[k][0]);
-                if (pr < p.hc_prob) {
-                    const double ud = uam_u32d(odd ? hw[k][3] : hw[k][1]);
-                    const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
-                    s.hd[k] += deg * UAM_DEG2RAD;
-                    double isn, ics;
-                    uam_sincos_k(s.hd[k], &isn, &ics);
-                    s.vx[k] = sp[k] * ics;
-                    s.vy[k] = sp[k] * isn;
+                if constexpr (!M4) {
+                    if (!odd) mcts_philox(rng, fp, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
+                    const double pr = uam_u32d(odd ? hw[k][2] : hw[k][0]);
+                    if (pr < p.hc_prob) {
+                        const double ud = uam_u32d(odd ? hw[k][3] : hw[k][1]);
+                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                        s.hd[k] += deg * UAM_DEG2RAD;
+                        double isn, ics;
+                        uam_sincos_k(s.hd[k], &isn, &ics);
+                        s.vx[k] = sp[k] * ics;
+                        s.vy[k] = sp[k] * isn;
+                    }
                 }
             }
         }
@@ -182,7 +213,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         for (int k = 0; k < K; k++) {
             const int i = lane + 64 * k;
             const double dx = s.x[k] - oxf, dy = s.y[k] - oyf;
-            near = near || (i < p.N && (dx * dx + dy * dy) < p.sep2);
+            near = near || (i < p.Nsim && (dx * dx + dy * dy) < p.sep2);
         }
         if (__any(near)) { flags = 2u; fe = f; break; }
         if ((goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                        /* :109-112 */
@@ -211,11 +242,12 @@ __device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const dou
     for (int k = 0; k < K; k++) {
         const int i = lane + 64 * k;
         const bool ok = i < p.N;
-        const double* it = root + 6 * (size_t)(ok ? i : 0);
+        const double* it = root + (size_t)p.width * (size_t)(ok ? i : 0);
         s.x[k] = ok ? it[0] : 0.0; s.y[k] = ok ? it[1] : 0.0; s.vx[k] = ok ? it[2] : 0.0; s.vy[k] = ok ? it[3] : 0.0;
-        sp[k] = ok ? it[4] : 0.0; s.hd[k] = ok ? it[5] : 0.0;
+        const bool six = ok && p.width == 6;
+        sp[k] = six ? it[4] : 0.0; s.hd[k] = six ? it[5] : 0.0;
     }
-    const double* own = root + 6 * (size_t)p.N;
+    const double* own = root + (size_t)p.width * (size_t)p.N;
     s.ox = own[0]; s.oy = own[1]; s.ovx = own[2]; s.ovy = own[3]; s.osp = own[4]; s.ohd = own[5];
     gx = own[6]; gy = own[7];
 }
@@ -257,7 +289,7 @@ __device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const dou
 }
 
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
-template <int K>
+template <int K, int MODEL>
 __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree trees[UAM_MCTS_WAVES_PER_BLOCK];
@@ -271,7 +303,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
     MctsState<K> rs;
     double sp[K];
     double gx, gy;
-    mcts_load_root<K>(p, p.roots + (size_t)root * (6 * p.N + 8), lane, rs, sp, gx, gy);
+    mcts_load_root<K>(p, p.roots + (size_t)root * (p.width * p.N + 8), lane, rs, sp, gx, gy);
     mcts_store_node<K>(p, pint, pown, 0, lane, rs);
     for (int i = lane; i < p.cap; i += 64) {
         t.n[i] = 0.0; t.q[i] = 0.0; t.rew[i] = 0.0;
@@ -299,7 +331,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
                 const int k = 8 - nc;
                 mcts_load_node<K>(p, pint, pown, v, lane, s);
-                flags = mcts_move<K>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s);
                 rng.mv = 1;
                 const int c = nn++;
                 depth = t.depth[v] + 1;
@@ -341,7 +373,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 uint32_t w4[4];
                 mcts_philox(rng, 0, UAM_MPH_ACTION, 0, w4);
                 const int a = (int)(((uint64_t)w4[0] * 9u) >> 32);          /* rollout_policy */
-                flags = mcts_move<K>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s);
                 rng.mv++;
                 depth++;
             }
@@ -383,7 +415,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 }
 
 /* one move() per state, no tree: parity / building block */
-template <int K>
+template <int K, int MODEL>
 __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_kernel(const UamMctsParams p)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -392,23 +424,24 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     MctsState<K> s;
     double sp[K];
     double gx, gy;
-    const size_t len = 6 * (size_t)p.N + 8;
+    const size_t len = (size_t)p.width * (size_t)p.N + 8;
     mcts_load_root<K>(p, p.roots + (size_t)root * len, lane, s, sp, gx, gy);
     MctsRng rng;
     rng.root = p.root_id0 + (uint32_t)root; rng.sim = p.sim_index; rng.mv = p.move_index; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
     const int a0 = p.actions_in[2 * (size_t)root], a1 = p.actions_in[2 * (size_t)root + 1];
-    const uint32_t flags = mcts_move<K>(p, rng, lane, sp, gx, gy, a0, a1, s);
+    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s);
     double* out = p.next_out + (size_t)root * len;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = lane + 64 * k;
         if (i < p.N) {
-            double* it = out + 6 * (size_t)i;
-            it[0] = s.x[k]; it[1] = s.y[k]; it[2] = s.vx[k]; it[3] = s.vy[k]; it[4] = sp[k]; it[5] = s.hd[k];
+            double* it = out + (size_t)p.width * (size_t)i;
+            it[0] = s.x[k]; it[1] = s.y[k]; it[2] = s.vx[k]; it[3] = s.vy[k];
+            if (p.width == 6) { it[4] = sp[k]; it[5] = s.hd[k]; }
         }
     }
     if (lane == 0) {
-        double* own = out + 6 * (size_t)p.N;
+        double* own = out + (size_t)p.width * (size_t)p.N;
         own[0] = s.ox; own[1] = s.oy; own[2] = s.ovx; own[3] = s.ovy; own[4] = s.osp; own[5] = s.ohd; own[6] = gx; own[7] = gy;
         p.flags_out[3 * (size_t)root] = (flags & 1u) ? 1 : 0;
         p.flags_out[3 * (size_t)root + 1] = (flags & 2u) ? 1 : 0;
@@ -417,24 +450,25 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     }
 }
 
-/* RAW6 root states straight from a RandIntruder env handle's SoA state (float64, no obs rounding) */
+/* root states straight from an env handle's SoA state (float64, no obs rounding): 6-wide rows when the
+ * handle holds speed/heading, else 4-wide */
 template <bool POS64>
-__global__ void uam_mcts_roots_kernel(const UamParams p, double* out)
+__global__ void uam_mcts_roots_kernel(const UamParams p, double* out, int width)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = p.N + 1;
     if (t >= p.B * per) return;
     const int e = t / per, i = t - e * per;
-    double* row = out + (size_t)e * (6 * p.N + 8);
+    double* row = out + (size_t)e * (width * p.N + 8);
     if (i < p.N) {
         const size_t k = (size_t)e * p.Np + i;
-        double* it = row + 6 * (size_t)i;
+        double* it = row + (size_t)width * (size_t)i;
         it[0] = POS64 ? ((const double*)p.s.px)[k] : (double)((const float*)p.s.px)[k];
         it[1] = POS64 ? ((const double*)p.s.py)[k] : (double)((const float*)p.s.py)[k];
         it[2] = (double)p.s.vx[k]; it[3] = (double)p.s.vy[k];
-        it[4] = p.s.isp[k]; it[5] = p.s.ihd[k];
+        if (width == 6) { it[4] = p.s.isp[k]; it[5] = p.s.ihd[k]; }
     } else {
-        double* own = row + 6 * (size_t)p.N;
+        double* own = row + (size_t)width * (size_t)p.N;
         own[0] = (double)p.s.own_x[e]; own[1] = (double)p.s.own_y[e]; own[2] = p.s.own_vx[e]; own[3] = p.s.own_vy[e];
         own[4] = p.s.own_s[e]; own[5] = p.s.own_h[e]; own[6] = p.s.goal_x[e]; own[7] = p.s.goal_y[e];
     }

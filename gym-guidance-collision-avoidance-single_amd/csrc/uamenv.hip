@@ -986,6 +986,7 @@ static int mcts_validate(const uam_mcts_config* c, int32_t B)
     if (c->struct_size != sizeof(uam_mcts_config)) return fail(UAM_EINVAL, "uam_mcts_config.struct_size mismatch");
     if (c->num_intruders < 1 || c->num_intruders > 64 * UAM_MCTS_MAX_SLOTS)
         return fail(UAM_EINVAL, "num_intruders must be in 1..%d (got %d)", 64 * UAM_MCTS_MAX_SLOTS, c->num_intruders);
+    if (c->model != UAM_MCTS_MODEL_RANDINTRU && c->model != UAM_MCTS_MODEL_STRAIGHT4) return fail(UAM_EINVAL, "bad MCTS model %d", c->model);
     /* node ids are bytes and 255 is the "no parent" sentinel: at most 255 nodes (root + one per simulation) */
     if (c->simulations < 1 || c->simulations + 1 > UAM_MCTS_MAX_NODES - 1)
         return fail(UAM_EINVAL, "simulations must be in 1..%d (got %d)", UAM_MCTS_MAX_NODES - 2, c->simulations);
@@ -1001,6 +1002,9 @@ static void mcts_fill(const uam_mcts_config* c, int32_t B, uint32_t root_id0, Ua
     memset(p, 0, sizeof(*p));
     p->B = B; p->N = c->num_intruders; p->K = (c->num_intruders + 63) / 64; p->Npad = p->K * 64;
     p->cap = c->simulations + 1; p->sims = c->simulations; p->depth = c->search_depth; p->frames = c->simulate_frame;
+    const bool m4 = c->model == UAM_MCTS_MODEL_STRAIGHT4;
+    p->width = m4 ? 4 : 6;
+    p->Nsim = m4 ? (4 * c->num_intruders + 8 - 9) / 4 : c->num_intruders;      /* nodes_single.py:47 */
     p->seed_lo = (uint32_t)c->seed; p->seed_hi = (uint32_t)(c->seed >> 32); p->root_id0 = root_id0;
     p->W = c->window_width; p->H = c->window_height; p->sep2 = sq_threshold_f64(c->minimum_separation);
     p->min_speed = c->min_speed; p->max_speed = c->max_speed; p->d_speed = c->d_speed;
@@ -1034,12 +1038,23 @@ extern "C" int uam_mcts_best_action(const uam_mcts_config* c, int device_id, con
     p.actions_out = actions_out; p.child_q_out = child_q_out; p.child_n_out = child_n_out;
     dim3 grid((B + UAM_MCTS_WAVES_PER_BLOCK - 1) / UAM_MCTS_WAVES_PER_BLOCK), block(64 * UAM_MCTS_WAVES_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-    switch (p.K) {
-    case 1: hipLaunchKernelGGL((uam_mcts_search_kernel<1>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((uam_mcts_search_kernel<2>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((uam_mcts_search_kernel<3>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((uam_mcts_search_kernel<4>), grid, block, 0, st, p); break;
+#define UAM_MCTS_LAUNCH(KERNEL)                                                                             \
+    if (c->model == UAM_MCTS_MODEL_STRAIGHT4) {                                                            \
+        switch (p.K) {                                                                                     \
+        case 1: hipLaunchKernelGGL((KERNEL<1, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<2, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
+        case 3: hipLaunchKernelGGL((KERNEL<3, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
+        default: hipLaunchKernelGGL((KERNEL<4, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;  \
+        }                                                                                                  \
+    } else {                                                                                               \
+        switch (p.K) {                                                                                     \
+        case 1: hipLaunchKernelGGL((KERNEL<1, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<2, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
+        case 3: hipLaunchKernelGGL((KERNEL<3, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
+        default: hipLaunchKernelGGL((KERNEL<4, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;  \
+        }                                                                                                  \
     }
+    UAM_MCTS_LAUNCH(uam_mcts_search_kernel)
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
@@ -1059,12 +1074,7 @@ extern "C" int uam_mcts_move(const uam_mcts_config* c, int device_id, const doub
     p.sim_index = sim_index; p.move_index = move_index;
     dim3 grid((B + UAM_MCTS_WAVES_PER_BLOCK - 1) / UAM_MCTS_WAVES_PER_BLOCK), block(64 * UAM_MCTS_WAVES_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-    switch (p.K) {
-    case 1: hipLaunchKernelGGL((uam_mcts_move_kernel<1>), grid, block, 0, st, p); break;
-    case 2: hipLaunchKernelGGL((uam_mcts_move_kernel<2>), grid, block, 0, st, p); break;
-    case 3: hipLaunchKernelGGL((uam_mcts_move_kernel<3>), grid, block, 0, st, p); break;
-    default: hipLaunchKernelGGL((uam_mcts_move_kernel<4>), grid, block, 0, st, p); break;
-    }
+    UAM_MCTS_LAUNCH(uam_mcts_move_kernel)
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
@@ -1072,15 +1082,15 @@ extern "C" int uam_mcts_move(const uam_mcts_config* c, int device_id, const doub
 extern "C" int uam_mcts_roots_from_env(uam_env* e, double* roots_out, void* stream)
 {
     if (!e || !roots_out) return fail(UAM_EINVAL, "NULL argument");
-    if (!e->hold_sh) return fail(UAM_EINVAL, "the env does not hold intruder speed/heading (needs the RandIntruder / RAW6 variant)");
+    const int width = e->hold_sh ? 6 : 4;     /* nodes_single_randintru.py / nodes_single.py state layouts */
     HIP_TRY(hipSetDevice(e->device));
     UamParams p;
     fill_params(e, &p);
     const int total = e->cfg.num_envs * (e->cfg.num_intruders + 1);
     if (e->cfg.precision == UAM_POS_EXACT)
-        hipLaunchKernelGGL((uam_mcts_roots_kernel<true>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, roots_out);
+        hipLaunchKernelGGL((uam_mcts_roots_kernel<true>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, roots_out, width);
     else
-        hipLaunchKernelGGL((uam_mcts_roots_kernel<false>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, roots_out);
+        hipLaunchKernelGGL((uam_mcts_roots_kernel<false>), dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, roots_out, width);
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }

@@ -2,16 +2,23 @@
 Algorithms/MCTS/search_single.py:8-13 for B root states in one launch (one wavefront per root).
 
 A root state is what the reference builds with `SingleAircraftState(state=last_observation)` from the
-RandIntruder env's raw observation (Algorithms/MCTS/Agent_RandInt.py:38-41): float64 `[B, 6N+8]`.
+env's raw observation: float64 `[B, 6N+8]` for the RandIntruder env and nodes_single_randintru.py
+(Algorithms/MCTS/Agent_RandInt.py:38-41, `model="randintru"`), `[B, 4N+8]` for SingleAircraftMCTSEnv and
+nodes_single.py (Algorithms/MCTS/Agent.py:36-40, `model="straight4"`, upstream quirks included).
 """
 import ctypes as C
 
 from . import _capi as capi
 
 
+MODELS = {"randintru": 0, "straight4": 1}
+
+
 def mcts_config(num_intruders, **over):
     cfg = capi.UamMctsConfig()
     capi.check(capi.lib().uam_mcts_config_default(C.byref(cfg), int(num_intruders)))
+    if isinstance(over.get("model"), str):
+        over["model"] = MODELS[over["model"]]
     for k, v in over.items():
         if not hasattr(cfg, k):
             raise AttributeError("uam_mcts_config has no field %r" % k)
@@ -30,7 +37,7 @@ class BatchedMCTS:
                                    (device if isinstance(device, int) else torch.device(device).index or 0))
         self.cfg = cfg if cfg is not None else mcts_config(num_intruders, seed=int(seed) & 0xFFFFFFFFFFFFFFFF, **over)
         self.N = int(self.cfg.num_intruders)
-        self.state_dim = 6 * self.N + 8
+        self.state_dim = (4 if int(self.cfg.model) == 1 else 6) * self.N + 8
         self._ws = None
         self.decisions = 0
 
@@ -45,8 +52,12 @@ class BatchedMCTS:
         return r
 
     def roots_from_env(self, env):
-        """float64 root states straight from a RandIntruder `BatchedSingleAircraftEnv`'s device state."""
+        """float64 root states straight from a `BatchedSingleAircraftEnv`'s device state (RandIntruder env for
+        the 6-wide model, any straight-line env for the 4-wide one)."""
         torch = self._torch
+        held = int(env.cfg.dynamics) == capi.DYN_RANDINTRUDER or int(env.cfg.obs_mode) == capi.OBS_RAW6
+        if (6 if held else 4) * self.N + 8 != self.state_dim or int(env.cfg.num_intruders) != self.N:
+            raise ValueError("env variant / intruder count does not match this planner's state layout")
         out = torch.empty((env.num_envs, self.state_dim), dtype=torch.float64, device=self.device)
         capi.check(self._lib.uam_mcts_roots_from_env(env._h, out.data_ptr(), self._stream()))
         return out

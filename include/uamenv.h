@@ -273,13 +273,24 @@ int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float*
  * heading] + goal[x,y] (6N+8 float64).  Randomness is Philox (key = seed; counter = (root id,
  * sim<<4 | move, frame<<8 | purpose, intruder)), so results are independent of batching.
  * ====================================================================================================== */
+enum {
+    UAM_MCTS_MODEL_RANDINTRU = 0, /* nodes_single_randintru.py:39-114: state [x,y,vx,vy,speed,heading]*N + own(6) + goal(2)
+                                     (6N+8), intruders change heading at random; planner of Agent_RandInt.py */
+    UAM_MCTS_MODEL_STRAIGHT4 = 1  /* nodes_single.py:39-100: state [x,y,vx,vy]*N + own(6) + goal(2) (4N+8), straight
+                                     intruders; planner of Agent.py on SingleAircraftMCTSEnv observations.  Two upstream
+                                     quirks are reproduced, not corrected: only the first (len - 9) // 4 = N - 1
+                                     intruders are moved and checked (:47), and every frame re-derives the speed from
+                                     the ownship's previous vy, speed = clip(state[-5]) (:60), so the speed command
+                                     has no effect */
+};
+
 typedef struct uam_mcts_config {
     uint32_t struct_size;
     int32_t  num_intruders;      /* N, 1..256 */
     int32_t  simulations;        /* Config.no_simulation = 100   config_single.py:60; 1..254 */
     int32_t  search_depth;       /* Config.search_depth  = 3     config_single.py:61 */
     int32_t  simulate_frame;     /* Config.simulate_frame = 10   config_single.py:59 */
-    int32_t  reserved0;
+    int32_t  model;              /* UAM_MCTS_MODEL_*: which SingleAircraftState.move is restated */
     uint64_t seed;
     double window_width, window_height, minimum_separation;                 /* config_single.py:6-7,16 */
     double min_speed, max_speed, d_speed, speed_sigma, position_sigma;      /* :23-27 */
@@ -291,8 +302,9 @@ typedef struct uam_mcts_config {
 
 int uam_mcts_config_default(uam_mcts_config* cfg, int32_t num_intruders);
 
-/* Root states of every env of a RAW6 (RandIntruder) handle, straight from its SoA state (float64, no
- * float32 observation rounding): roots_out = double[B, 6N+8] device. */
+/* Root states of every env of a handle, straight from its SoA state (float64, no float32 observation
+ * rounding): roots_out = double[B, 6N+8] device for a handle that holds speed/heading (RandIntruder
+ * dynamics or RAW6 observation: UAM_MCTS_MODEL_RANDINTRU), double[B, 4N+8] otherwise (UAM_MCTS_MODEL_STRAIGHT4). */
 int uam_mcts_roots_from_env(uam_env* env, double* roots_out, void* stream);
 
 /* MCTS(root).best_action(simulations, search_depth) for B roots at once, one wavefront per root.

@@ -64,7 +64,7 @@ class UamMctsConfig(C.Structure):
     """Mirror of `uam_mcts_config` (include/uamenv.h)."""
     _fields_ = [
         ("struct_size", C.c_uint32), ("num_intruders", C.c_int32), ("simulations", C.c_int32),
-        ("search_depth", C.c_int32), ("simulate_frame", C.c_int32), ("reserved0", C.c_int32),
+        ("search_depth", C.c_int32), ("simulate_frame", C.c_int32), ("model", C.c_int32),
         ("seed", C.c_uint64),
         ("window_width", C.c_double), ("window_height", C.c_double), ("minimum_separation", C.c_double),
         ("min_speed", C.c_double), ("max_speed", C.c_double), ("d_speed", C.c_double),

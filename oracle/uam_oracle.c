@@ -971,10 +971,76 @@ static double mcts_metric(const mcts_ctx* m, double x1, double y1, double x2, do
 }
 
 /* SingleAircraftState.move, nodes_single_randintru.py:39-114 */
+static int mcts_width(const uam_mcts_config* c) { return c->model == UAM_MCTS_MODEL_STRAIGHT4 ? 4 : 6; }
+static int mcts_len(const uam_mcts_config* c) { return mcts_width(c) * c->num_intruders + 8; }
+
+/* SingleAircraftState.move of the 4-wide model, Algorithms/MCTS/nodes_single.py:39-100.  Quirks kept: only the
+ * first (len - 9) // 4 = N - 1 intruders are moved and checked (:47); `state[-4] += acceleration` is dead
+ * because the next line re-derives the speed from state[-5], the ownship's previous vy (:59-60). */
+static void mcts_move4(mcts_ctx* m, const double* s_in, int a0, int a1, double* s, int* hit_wall, int* conflict,
+                       int* reach_goal)
+{
+    const uam_mcts_config* c = m->c;
+    const int N = c->num_intruders, len = 4 * N + 8;
+    const int near = (len - 9) / 4;
+    memcpy(s, s_in, sizeof(double) * (size_t)len);
+    double* own = s + 4 * N;     /* x, y, vx, vy, speed, heading, goalx, goaly */
+    *hit_wall = *conflict = *reach_goal = 0;
+    const double d_heading = (a0 - 1) * c->d_heading;
+    const double accel = (a1 - 1) * c->d_speed;
+    for (int f = 0; f < c->simulate_frame; f++) {
+        for (int i = 0; i < near; i++) {
+            double* it = s + 4 * i;
+            double nx_, ny_;
+            if (m->rng_mode == UAM_RNG_MT19937) {
+                nx_ = 0.0 + c->position_sigma * mt_gauss(&m->fake, &m->mt);
+                it[0] += it[2] + nx_;
+                ny_ = 0.0 + c->position_sigma * mt_gauss(&m->fake, &m->mt);
+                it[1] += it[3] + ny_;
+            } else {
+                if (c->position_sigma != 0.0) {
+                    double z0, z1;
+                    mphilox_normals(m, (uint32_t)f, MPH_POS, (uint32_t)i, &z0, &z1);
+                    nx_ = 0.0 + c->position_sigma * z0; ny_ = 0.0 + c->position_sigma * z1;
+                } else { nx_ = 0.0; ny_ = 0.0; }
+                it[0] += it[2] + nx_;
+                it[1] += it[3] + ny_;
+            }
+        }
+        double zs, zh;
+        if (m->rng_mode == UAM_RNG_MT19937) {
+            zs = mt_gauss(&m->fake, &m->mt);
+            zh = mt_gauss(&m->fake, &m->mt);
+        } else {
+            double z0, z1;
+            zs = 0.0;
+            if (c->speed_sigma != 0.0) { mphilox_normals(m, (uint32_t)f >> 1, MPH_OWN_S, 0, &z0, &z1); zs = (f & 1) ? z1 : z0; }
+            mphilox_normals(m, (uint32_t)f >> 1, MPH_OWN_H, 0, &z0, &z1);
+            zh = (f & 1) ? z1 : z0;
+        }
+        own[4] += accel;                                                      /* :59, overwritten by :60 */
+        own[4] = fmax(c->min_speed, fmin(own[3], c->max_speed));              /* :60: state[-5] is the ownship's vy */
+        own[4] += 0.0 + c->speed_sigma * zs;
+        own[5] += d_heading;
+        own[5] += 0.0 + c->heading_sigma * zh;
+        double sn, cs;
+        m_sincos(&m->fake, own[5], &sn, &cs);
+        const double ovx = own[4] * cs, ovy = own[4] * sn;
+        own[0] += ovx; own[1] += ovy; own[2] = ovx; own[3] = ovy;
+        const double ox = own[0], oy = own[1];
+        if (!(0 < ox && ox < c->window_width) || !(0 < oy && oy < c->window_height)) { *hit_wall = 1; break; }   /* :78-80 */
+        for (int i = 0; i < near; i++)
+            if (mcts_metric(m, s[4 * i], s[4 * i + 1], ox, oy) < c->minimum_separation) { *conflict = 1; break; }
+        if (*conflict) break;
+        if (mcts_metric(m, ox, oy, own[6], own[7]) < c->minimum_separation) { *reach_goal = 1; break; }          /* :93 */
+    }
+}
+
 static void mcts_move(mcts_ctx* m, const double* s_in, int a0, int a1, double* s, int* hit_wall, int* conflict,
                       int* reach_goal)
 {
     const uam_mcts_config* c = m->c;
+    if (c->model == UAM_MCTS_MODEL_STRAIGHT4) { mcts_move4(m, s_in, a0, a1, s, hit_wall, conflict, reach_goal); return; }
     const int N = c->num_intruders, len = 6 * N + 8;
     memcpy(s, s_in, sizeof(double) * (size_t)len);
     double* own = s + 6 * N;     /* x, y, vx, vy, speed, heading, goalx, goaly */
@@ -1053,7 +1119,7 @@ static double mcts_reward(const mcts_ctx* m, const double* s, int hit_wall, int 
 {
     if (hit_wall || conflict) return 0.0;
     if (reach_goal) return 1.0;
-    const double* own = s + 6 * m->c->num_intruders;
+    const double* own = s + mcts_width(m->c) * m->c->num_intruders;
     double dx = own[0] - own[6], dy = own[1] - own[7];
     double d = m->math_impl == ORC_MATH_LIBM ? sqrt(pow(dx, 2.0) + pow(dy, 2.0)) : sqrt(dx * dx + dy * dy);
     return 1 - d / m->c->reward_div;
@@ -1111,7 +1177,7 @@ void orc_mcts_best_action(const uam_mcts_config* cfg, int rng_mode, int math_imp
                           const double* root_state, int32_t* best_action2, int32_t* child_action18,
                           double* child_q9, double* child_n9, double* root_n_out, int* n_nodes_out, int* rng_pos_out)
 {
-    const int len = 6 * cfg->num_intruders + 8;
+    const int len = mcts_len(cfg);
     const int cap = cfg->simulations + 1;
     mcts_ctx m;
     mcts_ctx_init(&m, cfg, rng_mode, math_impl, np_seed, root_id);

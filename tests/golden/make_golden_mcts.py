@@ -11,6 +11,10 @@ Same rules as make_golden.py: data only, reference imported unmodified under the
       states [C, 6N+8], seeds [C], sims, depth
       best_action [C,2], child_action [C,9,2], child_q [C,9], child_n [C,9], root_n [C], rng_pos [C],
       n_nodes [C]
+  g16_mcts4_move_*, g17_mcts4_search_*: the same for the 4-wide model Algorithms/MCTS/nodes_single.py (what
+      Agent.py plans with on SingleAircraftMCTSEnv observations): states [C, 4N+8].  Upstream quirks recorded
+      as they are: the last intruder is ignored ((len - 9) // 4) and the speed is re-derived from the ownship's
+      previous vy (state[-5]) every frame.
 """
 import os
 import sys
@@ -31,8 +35,8 @@ def load_mcts(ref):
     return Config, m_ri, nodes, search, config_single.Config
 
 
-def collect_roots(Config, m_ri, N, seed, count, stride):
-    """Root observations from a RandIntruder env driven by the goal-seeking heuristic."""
+def collect_roots(Config, m_ri, N, seed, count, stride, pair_action=False):
+    """Root observations from a RandIntruder (or MCTSEnv) env driven by the goal-seeking heuristic."""
     Config.intruder_size = N
     np.random.seed(seed)
     env = m_ri.SingleAircraftEnv()
@@ -54,7 +58,7 @@ def mt_pos():
     return int(np.random.get_state()[2])
 
 
-def gen_moves(nodes, roots, name):
+def gen_moves(nodes, roots, name, width=6):
     states, actions, seeds, nxt, flags, rewards, pos = [], [], [], [], [], [], []
     k = 0
     for r in roots:
@@ -72,13 +76,13 @@ def gen_moves(nodes, roots, name):
                 flags.append((out.hit_wall, out.conflict, out.reach_goal))
                 rewards.append(float(out.reward()))
                 pos.append(mt_pos())
-    mg.save(name, dict(N=(roots.shape[1] - 8) // 6),
+    mg.save(name, dict(N=(roots.shape[1] - 8) // width, width=width),
             dict(states=np.stack(states), actions=np.asarray(actions, np.int32), seeds=np.asarray(seeds, np.uint32),
                  next_states=np.stack(nxt), flags=np.asarray(flags, np.uint8), rewards=np.asarray(rewards),
                  rng_pos=np.asarray(pos, np.int32)))
 
 
-def gen_search(nodes, search, roots, name, sims, depth):
+def gen_search(nodes, search, roots, name, sims, depth, width=6):
     best, ca, cq, cn, rn, pos, nn, seeds = [], [], [], [], [], [], [], []
 
     def count_nodes(n):
@@ -102,7 +106,7 @@ def gen_search(nodes, search, roots, name, sims, depth):
         pos.append(mt_pos())
         nn.append(count_nodes(root))
         seeds.append(seed)
-    mg.save(name, dict(N=(roots.shape[1] - 8) // 6, sims=sims, depth=depth),
+    mg.save(name, dict(N=(roots.shape[1] - 8) // width, sims=sims, depth=depth, width=width),
             dict(states=roots, seeds=np.asarray(seeds, np.uint32), best_action=np.asarray(best, np.int32),
                  child_action=np.stack(ca), child_q=np.stack(cq), child_n=np.stack(cn), root_n=np.asarray(rn),
                  rng_pos=np.asarray(pos, np.int32), n_nodes=np.asarray(nn, np.int32)))
@@ -136,6 +140,35 @@ def main():
     try:
         roots = collect_roots(Config, m_ri, 8, 33, 6, 41)
         gen_moves(nodes, roots, "g11_mcts_move_n8_noisy")
+    finally:
+        mcfg.position_sigma, mcfg.speed_sigma = keep
+    main4(Config, mcfg, search)
+
+
+def main4(Config, mcfg, search):
+    """The 4-wide model (nodes_single.py) on SingleAircraftMCTSEnv observations."""
+    import nodes_single as nodes4
+    import SingleAircraftMCTSEnv as m_mcts
+    for N, seed in ((8, 41), (20, 42)):
+        roots = collect_roots(Config, m_mcts, N, seed, 10, 37)
+        gen_moves(nodes4, roots, "g16_mcts4_move_n%d" % N, width=4)
+        gen_search(nodes4, search, roots[:6], "g17_mcts4_search_n%d" % N, mcfg.no_simulation, mcfg.search_depth, width=4)
+    base = collect_roots(Config, m_mcts, 8, 44, 3, 29)
+    stress = []
+    for r in base:
+        own = r[-8:].copy()
+        hx, hy = np.cos(own[5]), np.sin(own[5])
+        a = r.copy(); a[0] = own[0] + 30 * hx; a[1] = own[1] + 30 * hy; a[2] = -hx; a[3] = -hy; stress.append(a)
+        b = r.copy(); b[-8] = 796.5; b[-7] = 400.0; b[-3] = 0.0; b[0:32:4] = np.linspace(100, 500, 8); b[1:32:4] = 100.0; stress.append(b)
+        c = r.copy(); c[-2] = own[0] + 25 * hx; c[-1] = own[1] + 25 * hy; stress.append(c)
+        # the LAST intruder sits on the ownship's path: the model ignores it ((len - 9) // 4), no conflict
+        d = r.copy(); d[28] = own[0] + 20 * hx; d[29] = own[1] + 20 * hy; d[30] = -hx; d[31] = -hy; stress.append(d)
+    gen_moves(nodes4, np.stack(stress), "g16_mcts4_move_n8_flags", width=4)
+    keep = (mcfg.position_sigma, mcfg.speed_sigma)
+    mcfg.position_sigma, mcfg.speed_sigma = 10 / 30, 2 / 30
+    try:
+        roots = collect_roots(Config, m_mcts, 8, 43, 5, 41)
+        gen_moves(nodes4, roots, "g16_mcts4_move_n8_noisy", width=4)
     finally:
         mcfg.position_sigma, mcfg.speed_sigma = keep
 

@@ -118,3 +118,65 @@ def test_roots_from_env_feed_the_planner(uamenv):
         assert bool(((acts >= 0) & (acts <= 2)).all())
         env.step(acts)
     env.close()
+
+
+# ---------------------------------------------------------------- the 4-wide model (Algorithms/MCTS/nodes_single.py)
+@pytest.mark.parametrize("name,over", [("g16_mcts4_move_n8", {}), ("g16_mcts4_move_n20", {}), ("g16_mcts4_move_n8_flags", {}),
+                                       ("g16_mcts4_move_n8", dict(position_sigma=10 / 30, speed_sigma=2 / 30))])
+def test_straight4_move_matches_oracle_bit_exact(uamenv, oracle, name, over):
+    roots = _roots(name)
+    N = (roots.shape[1] - 8) // 4
+    planner = uamenv.BatchedMCTS(N, seed=99, model="straight4", **over)
+    assert planner.state_dim == 4 * N + 8
+    ocfg = _ocfg(oracle, planner.cfg)
+    states = np.repeat(roots, 9, axis=0)
+    actions = np.tile(np.array([(a, b) for a in range(3) for b in range(3)], dtype=np.int32), (len(roots), 1))
+    nxt, flags, rew = planner.move(states, actions, root_id0=40, sim=7, move=2)
+    nxt, flags, rew = nxt.cpu().numpy(), flags.cpu().numpy(), rew.cpu().numpy()
+    seen = np.zeros(3, int)
+    for k in range(len(states)):
+        on, of, orw, _ = oracle.mcts_move(ocfg, states[k], actions[k], rng_mode=oracle.RNG_PHILOX,
+                                         math_impl=oracle.MATH_PORTABLE, root_id=40 + k, sim=7, move=2)
+        assert np.array_equal(flags[k], of), (k, flags[k], of)
+        assert np.array_equal(nxt[k], on), (k, np.abs(nxt[k] - on).max())
+        assert rew[k] == orw
+        seen += of
+    assert np.array_equal(nxt[:, 4 * (N - 1):4 * N], states[:, 4 * (N - 1):4 * N]), "the last intruder is never moved (upstream quirk)"
+    if name.endswith("flags"):
+        assert seen.min() > 0
+
+
+@pytest.mark.parametrize("name,sims,depth", [("g17_mcts4_search_n8", 100, 3), ("g17_mcts4_search_n20", 100, 3),
+                                             ("g17_mcts4_search_n8", 200, 4)])
+def test_straight4_best_action_matches_oracle_bit_exact(uamenv, oracle, name, sims, depth):
+    roots = gu.load(name)["states"]
+    N = (roots.shape[1] - 8) // 4
+    planner = uamenv.BatchedMCTS(N, seed=5, simulations=sims, search_depth=depth, model="straight4")
+    ocfg = _ocfg(oracle, planner.cfg)
+    acts, cq, cn = planner.best_action(roots, root_id0=1000, want_children=True)
+    acts, cq, cn = acts.cpu().numpy(), cq.cpu().numpy(), cn.cpu().numpy()
+    for k in range(len(roots)):
+        o = oracle.mcts_best_action(ocfg, roots[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE,
+                                    root_id=1000 + k)
+        assert np.array_equal(cn[k], o["child_n"]), (k, cn[k], o["child_n"])
+        assert np.array_equal(cq[k], o["child_q"]), (k, cq[k] - o["child_q"])
+        assert np.array_equal(acts[k], o["best_action"]), (k, acts[k], o["best_action"])
+
+
+def test_agent_loop_on_mcts_env(uamenv):
+    """Agent.py loop shape: SingleAircraftMCTSEnv obs -> 4-wide root state -> best action -> env.step."""
+    import torch
+    B, N = 64, 8
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="mcts", seed=2)
+    obs = env.reset()
+    planner = uamenv.BatchedMCTS(N, seed=2, simulations=30, model="straight4")
+    roots = planner.roots_from_env(env)
+    assert roots.shape == (B, 4 * N + 8) and roots.dtype == torch.float64
+    assert torch.allclose(roots.float(), obs, atol=1e-4)       # same numbers as the raw observation
+    with pytest.raises(ValueError):
+        uamenv.BatchedMCTS(N).roots_from_env(env)              # 6-wide planner on a 4-wide env
+    for t in range(3):
+        acts = planner.best_action(planner.roots_from_env(env), root_id0=t * B)
+        assert bool(((acts >= 0) & (acts <= 2)).all())
+        env.step(acts)
+    env.close()

@@ -7,15 +7,22 @@ import pytest
 
 import golden_util as gu
 
-MOVE_FIXTURES = ["g11_mcts_move_n8", "g11_mcts_move_n20", "g11_mcts_move_n8_flags", "g11_mcts_move_n8_noisy"]
-SEARCH_FIXTURES = ["g12_mcts_search_n8", "g12_mcts_search_n20", "g12_mcts_search_n8_flags"]
+MOVE_FIXTURES = ["g11_mcts_move_n8", "g11_mcts_move_n20", "g11_mcts_move_n8_flags", "g11_mcts_move_n8_noisy",
+                 # the 4-wide model of Algorithms/MCTS/nodes_single.py (Agent.py's planner)
+                 "g16_mcts4_move_n8", "g16_mcts4_move_n20", "g16_mcts4_move_n8_flags", "g16_mcts4_move_n8_noisy"]
+SEARCH_FIXTURES = ["g12_mcts_search_n8", "g12_mcts_search_n20", "g12_mcts_search_n8_flags",
+                   "g17_mcts4_search_n8", "g17_mcts4_search_n20"]
+
+
+def _model(fx):
+    return 1 if int(fx.get("meta_width", 6)) == 4 else 0
 
 
 def _cfg(oracle, fx, name):
     over = {}
     if name.endswith("noisy"):
         over = dict(position_sigma=10 / 30, speed_sigma=2 / 30)
-    return oracle.mcts_config(int(fx["meta_N"]), **over)
+    return oracle.mcts_config(int(fx["meta_N"]), model=_model(fx), **over)
 
 
 @pytest.mark.parametrize("name", MOVE_FIXTURES)
@@ -30,12 +37,17 @@ def test_move_matches_reference_bit_exact(oracle, name):
         assert pos == int(fx["rng_pos"][k]), (name, k, "stream position")
     if name.endswith("flags"):
         assert fx["flags"].sum(0).min() > 0, "fixture must exercise hit_wall, conflict and reach_goal"
+    if name == "g16_mcts4_move_n8_flags":
+        # upstream quirk: the last intruder is never moved ((len - 9) // 4 = N - 1)
+        N = int(fx["meta_N"])
+        assert np.array_equal(fx["next_states"][:, 4 * (N - 1):4 * N], fx["states"][:, 4 * (N - 1):4 * N])
 
 
 @pytest.mark.parametrize("name", SEARCH_FIXTURES)
 def test_best_action_matches_reference_bit_exact(oracle, name):
     fx = gu.load(name)
-    cfg = oracle.mcts_config(int(fx["meta_N"]), simulations=int(fx["meta_sims"]), search_depth=int(fx["meta_depth"]))
+    cfg = oracle.mcts_config(int(fx["meta_N"]), simulations=int(fx["meta_sims"]), search_depth=int(fx["meta_depth"]),
+                             model=_model(fx))
     for k in range(len(fx["seeds"])):
         out = oracle.mcts_best_action(cfg, fx["states"][k], np_seed=int(fx["seeds"][k]))
         assert np.array_equal(out["best_action"], fx["best_action"][k]), (name, k)
