@@ -19,8 +19,9 @@
  * instruction stream is issued once per wave either way.
  *
  * Randomness: Philox4x32-10, key = seed, counter = (root id, sim<<4 | move, (frame>>1)<<8 | purpose,
- * intruder).  Heading-change draws and the ownship normals are produced per FRAME PAIR (one block / one
- * Box-Muller pair serves two frames).  Zero sigmas (the shipped MCTS config has position_sigma =
+ * intruder).  The ownship normals are produced per FRAME PAIR (one Box-Muller pair serves two frames), the
+ * heading-change draws per FRAME QUAD: word frame&3 of the block is the Bernoulli uniform p and a change takes its
+ * second uniform as p / hc_prob (uniform on [0,1) given p < hc_prob).  Zero sigmas (the shipped MCTS config has position_sigma =
  * speed_sigma = 0) draw nothing: adding N(0,0) is the identity.
  */
 #ifndef UAM_MCTS_DEVICE_H
@@ -46,6 +47,7 @@ struct UamMctsParams {
     uint32_t sim_index, move_index;      /* uam_mcts_move only */
     double W, H, sep2, min_speed, max_speed, d_speed, speed_sigma, position_sigma, d_heading, heading_sigma,
         hc_prob, hc_max_deg, c_param, reward_div;
+    unsigned long long hc_thr;           /* ceil(hc_prob * 2^32): word * 2^-32 < hc_prob  <=>  word < hc_thr */
     const double* roots;                 /* [B][6N+8] */
     double* pool_int;                    /* [B][cap][5][Npad]: x, y, vx, vy, heading of expandable nodes */
     double* pool_own;                    /* [B][cap][8] */
@@ -74,6 +76,17 @@ template <int K> struct MctsState {
 
 struct MctsRng { uint32_t root, sim, mv, k0, k1; };
 
+/* value of lane l (wave-uniform l) for the whole wave: v_readlane into scalar registers, no LDS round trip
+ * (a ds_bpermute broadcast costs a full LDS latency on every step of the ownship recurrences) */
+__device__ __forceinline__ double lane_bcast(double v, int l)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 __device__ __forceinline__ void mcts_philox(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx, uint32_t* w)
 {
     uam_philox(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, r.k0, r.k1, w);
@@ -100,11 +113,25 @@ __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepai
  * sincos of every frame's heading (lane f = frame f) are evaluated ONCE in parallel instead of once per
  * frame wave-uniformly.  The recurrences themselves (speed clamp, heading, position sums) run in the
  * reference's order, sequentially, so every rounding is the reference's.  Needs frames <= 64. */
+/* Heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on positions, so
+ * all of a move's changes are drawn in a PRE-PASS; every changed heading goes into a wave-level LDS queue
+ * (slot = running ballot rank, frame-major), the queue's sincos are evaluated DENSELY (lane j takes entry j,
+ * j+64, ...: ~N entries per move instead of F sparse evaluations with ~10 % of the lanes active), and the frame
+ * loop picks its (heading, cos, sin) up by recomputing the same ballot rank.  Entries beyond the queue's
+ * capacity (never at the shipped 10 % rate, but possible) are evaluated in place as before. */
+#define UAM_MCTS_QCAP(K) (128 * (K))
+
 template <int K, int MODEL>
 __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
-                                     const double gx, const double gy, const int a0, const int a1, MctsState<K>& s)
+                                     const double gx, const double gy, const int a0, const int a1, MctsState<K>& s,
+                                     double* qbuf)
 {
     constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
+    constexpr int QCAP = UAM_MCTS_QCAP(K);
+    double* const qh = qbuf;              /* heading after the change */
+    double* const qc = qbuf + QCAP;       /* its cosine */
+    double* const qs = qbuf + 2 * QCAP;   /* its sine */
+    (void)qh; (void)qc; (void)qs;
     const int F = p.frames;
     const double d_heading = (double)(a0 - 1) * p.d_heading;
     const double accel = (double)(a1 - 1) * p.d_speed;
@@ -122,7 +149,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
         double spd = s.osp, hdg = s.ohd;
         for (int f = 0; f < F; f++) {
-            const double zsf = __shfl(zs, f), zhf = __shfl(zh, f);
+            const double zsf = lane_bcast(zs, f), zhf = lane_bcast(zh, f);
             spd += accel;
             spd = fmax(p.min_speed, fmin(spd, p.max_speed));
             spd += 0.0 + p.speed_sigma * zsf;
@@ -137,8 +164,8 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         /* ---- positions in frame order, :83-86 */
         double ox = s.ox, oy = s.oy;
         for (int f = 0; f < F; f++) {
-            ox += __shfl(my_vx, f);
-            oy += __shfl(my_vy, f);
+            ox += lane_bcast(my_vx, f);
+            oy += lane_bcast(my_vy, f);
             if (lane == f) { my_ox = ox; my_oy = oy; }
         }
     } else {
@@ -149,7 +176,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         double hdg = s.ohd;
         for (int f = 0; f < F; f++) {
             hdg += d_heading;
-            hdg += 0.0 + p.heading_sigma * __shfl(zh, f);
+            hdg += 0.0 + p.heading_sigma * lane_bcast(zh, f);
             if (lane == f) my_hd = hdg;
         }
         double sn, cs;
@@ -157,8 +184,8 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         double vyp = s.ovy, ox = s.ox, oy = s.oy;
         for (int f = 0; f < F; f++) {
             double spd = fmax(p.min_speed, fmin(vyp, p.max_speed));
-            spd += 0.0 + p.speed_sigma * __shfl(zs, f);
-            const double vx = spd * __shfl(cs, f), vy = spd * __shfl(sn, f);
+            spd += 0.0 + p.speed_sigma * lane_bcast(zs, f);
+            const double vx = spd * lane_bcast(cs, f), vy = spd * lane_bcast(sn, f);
             ox += vx; oy += vy; vyp = vy;
             if (lane == f) { my_sp = spd; my_vx = vx; my_vy = vy; my_ox = ox; my_oy = oy; }
         }
@@ -169,13 +196,56 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
     const unsigned long long wallm = __ballot(in_f && wall);
     const unsigned long long goalm = __ballot(in_f && (gdx * gdx + gdy * gdy) < p.sep2);
 
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    unsigned long long chg[K];            /* bit f: this intruder changes heading at frame f */
+    if constexpr (!M4) {
+        double hcur[K];
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { chg[k] = 0; hcur[k] = s.hd[k]; }
+        uint32_t hw[K][4];
+        for (int f = 0; f < F; f++) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int i = lane + 64 * k;
+                bool c = false;
+                if (i < p.N) {
+                    if ((f & 3) == 0) mcts_philox(rng, (uint32_t)f >> 2, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
+                    const uint32_t w = (f & 2) ? ((f & 1) ? hw[k][3] : hw[k][2]) : ((f & 1) ? hw[k][1] : hw[k][0]);
+                    c = (unsigned long long)w < p.hc_thr;
+                    if (c) {
+                        const double ud = uam_u32d(w) / p.hc_prob;
+                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                        hcur[k] += deg * UAM_DEG2RAD;
+                        chg[k] |= 1ull << f;
+                    }
+                }
+                const unsigned long long m = __ballot(c);
+                if (c) {
+                    const int idx = total + __popcll(m & lt_mask);
+                    if (idx < QCAP) qh[idx] = hcur[k];
+                }
+                total += __popcll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nq = total < QCAP ? total : QCAP;
+        for (int j = lane; j < nq; j += 64) {
+            double qsn, qcs;
+            uam_sincos_k(qh[j], &qsn, &qcs);
+            qc[j] = qcs; qs[j] = qsn;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
     uint32_t flags = 0;
     int fe = F - 1;
-    uint32_t hw[M4 ? 1 : K][4];
-    (void)hw; (void)sp;
+    int qbase = 0;
     for (int f = 0; f < F; f++) {
-        const uint32_t fp = (uint32_t)f >> 1;
-        const int odd = f & 1;
         /* ---- intruders: position += velocity (+ noise), Bernoulli heading change, :54-70 */
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -190,11 +260,20 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                 }
                 s.x[k] += s.vx[k] + nx_;
                 s.y[k] += s.vy[k] + ny_;
-                if constexpr (!M4) {
-                    if (!odd) mcts_philox(rng, fp, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
-                    const double pr = uam_u32d(odd ? hw[k][2] : hw[k][0]);
-                    if (pr < p.hc_prob) {
-                        const double ud = uam_u32d(odd ? hw[k][3] : hw[k][1]);
+            }
+            if constexpr (!M4) {
+                const bool c = (chg[k] >> f) & 1ull;
+                const unsigned long long m = __ballot(c);
+                if (c) {
+                    const int idx = qbase + __popcll(m & lt_mask);
+                    if (idx < QCAP) {
+                        s.hd[k] = qh[idx];
+                        s.vx[k] = sp[k] * qc[idx];
+                        s.vy[k] = sp[k] * qs[idx];
+                    } else {        /* queue overflow: redraw this frame's change and evaluate it here */
+                        uint32_t w4[4];
+                        mcts_philox(rng, (uint32_t)f >> 2, UAM_MPH_HEADCHG, (uint32_t)i, w4);
+                        const double ud = uam_u32d(w4[f & 3]) / p.hc_prob;
                         const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
                         s.hd[k] += deg * UAM_DEG2RAD;
                         double isn, ics;
@@ -203,11 +282,12 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                         s.vy[k] = sp[k] * isn;
                     }
                 }
+                qbase += __popcll(m);
             }
         }
         if ((wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                        /* :94-96 */
         /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
-        const double oxf = __shfl(my_ox, f), oyf = __shfl(my_oy, f);
+        const double oxf = lane_bcast(my_ox, f), oyf = lane_bcast(my_oy, f);
         bool near = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -218,9 +298,9 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         if (__any(near)) { flags = 2u; fe = f; break; }
         if ((goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                        /* :109-112 */
     }
-    s.ox = __shfl(my_ox, fe); s.oy = __shfl(my_oy, fe);
-    s.ovx = __shfl(my_vx, fe); s.ovy = __shfl(my_vy, fe);
-    s.osp = __shfl(my_sp, fe); s.ohd = __shfl(my_hd, fe);
+    s.ox = lane_bcast(my_ox, fe); s.oy = lane_bcast(my_oy, fe);
+    s.ovx = lane_bcast(my_vx, fe); s.ovy = lane_bcast(my_vy, fe);
+    s.osp = lane_bcast(my_sp, fe); s.ohd = lane_bcast(my_hd, fe);
     return flags;
 }
 
@@ -293,10 +373,12 @@ template <int K, int MODEL>
 __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree trees[UAM_MCTS_WAVES_PER_BLOCK];
+    __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
     if (root >= p.B) return;
     MctsTree& t = trees[wv];
+    double* const qbuf = queues[wv];
     double* pint = p.pool_int + (size_t)root * p.cap * 5 * p.Npad;
     double* pown = p.pool_own + (size_t)root * p.cap * 8;
 
@@ -331,7 +413,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
                 const int k = 8 - nc;
                 mcts_load_node<K>(p, pint, pown, v, lane, s);
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s, qbuf);
                 rng.mv = 1;
                 const int c = nn++;
                 depth = t.depth[v] + 1;
@@ -360,7 +442,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 const int b2 = __shfl_xor(best, o);
                 if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
             }
-            best = __shfl(best, 0);
+            best = lane_bcast(best, 0);
             v = t.child[v][best];
         }
         /* ---- rollout, nodes_single_randintru.py:212-218 */
@@ -373,7 +455,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
                 uint32_t w4[4];
                 mcts_philox(rng, 0, UAM_MPH_ACTION, 0, w4);
                 const int a = (int)(((uint64_t)w4[0] * 9u) >> 32);          /* rollout_policy */
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s, qbuf);
                 rng.mv++;
                 depth++;
             }
@@ -399,7 +481,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
             const int b2 = __shfl_xor(best, o);
             if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
         }
-        best = __shfl(best, 0);
+        best = lane_bcast(best, 0);
         if (lane == 0) {
             const int k = nc > 0 ? t.act[t.child[0][best]] : 4;
             p.actions_out[2 * (size_t)root] = k / 3;
@@ -418,6 +500,7 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 template <int K, int MODEL>
 __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_kernel(const UamMctsParams p)
 {
+    __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
     if (root >= p.B) return;
@@ -429,7 +512,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     MctsRng rng;
     rng.root = p.root_id0 + (uint32_t)root; rng.sim = p.sim_index; rng.mv = p.move_index; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
     const int a0 = p.actions_in[2 * (size_t)root], a1 = p.actions_in[2 * (size_t)root + 1];
-    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s);
+    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s, queues[wv]);
     double* out = p.next_out + (size_t)root * len;
 #pragma unroll
     for (int k = 0; k < K; k++) {

@@ -1011,6 +1011,10 @@ static void mcts_fill(const uam_mcts_config* c, int32_t B, uint32_t root_id0, Ua
     p->speed_sigma = c->speed_sigma; p->position_sigma = c->position_sigma;
     p->d_heading = c->d_heading; p->heading_sigma = c->heading_sigma;
     p->hc_prob = c->heading_change_prob; p->hc_max_deg = c->heading_change_max_deg;
+    {   /* word * 2^-32 < hc_prob  <=>  word < ceil(hc_prob * 2^32) (scaling by 2^32 is exact) */
+        const double t = c->heading_change_prob * 4294967296.0;
+        p->hc_thr = t <= 0.0 ? 0ull : (t >= 4294967296.0 ? 4294967296ull : (unsigned long long)ceil(t));
+    }
     p->c_param = c->c_param; p->reward_div = c->reward_div;
 }
 

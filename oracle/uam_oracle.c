@@ -912,8 +912,10 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
  * common.py (MCTSNode.best_child, rollout_policy) and search_single.py (MCTS.best_action, tree_policy).
  * Third-party arithmetic: NumPy scalar `x**2` is libm pow(x, 2.0) (differs from x*x by 1 ulp in ~0.09 %
  * of cases, probed); legacy RandomState.randint(9) = masked rejection on one 32-bit word per attempt. */
-/* Philox purposes; HEADCHG and the ownship noises are drawn per FRAME PAIR (counter word 2 carries frame>>1,
- * the frame's parity selects the half of the block) */
+/* Philox purposes; the ownship noises are drawn per FRAME PAIR (counter word 2 carries frame>>1, the frame's
+ * parity selects the half of the block).  HEADCHG is drawn per FRAME QUAD (counter word 2 carries frame>>2): word
+ * frame&3 is the Bernoulli uniform p, and a change takes its second uniform as p / heading_change_prob, which is
+ * uniform on [0,1) given p < heading_change_prob (one Philox block serves four frames). */
 enum { MPH_HEADCHG = 1, MPH_OWN_H = 2, MPH_POS = 3, MPH_ACTION = 4, MPH_OWN_S = 5 };
 
 typedef struct {
@@ -1068,9 +1070,9 @@ static void mcts_move(mcts_ctx* m, const double* s_in, int a0, int a1, double* s
                 it[0] += vx + nx_;
                 it[1] += vy + ny_;
                 uint32_t w[4];
-                mphilox(m, (uint32_t)f >> 1, MPH_HEADCHG, (uint32_t)i, w);
-                p = u32d(w[2 * (f & 1)]);
-                ud = u32d(w[2 * (f & 1) + 1]);
+                mphilox(m, (uint32_t)f >> 2, MPH_HEADCHG, (uint32_t)i, w);
+                p = u32d(w[f & 3]);
+                ud = p < c->heading_change_prob ? p / c->heading_change_prob : 0.0;
             }
             if (p < c->heading_change_prob) {                                 /* :64-70 */
                 double deg = -c->heading_change_max_deg + (c->heading_change_max_deg - (-c->heading_change_max_deg)) * ud;
