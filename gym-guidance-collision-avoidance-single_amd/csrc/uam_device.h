@@ -5,18 +5,23 @@
  * observe / policy kernels and the two RNGs (Philox4x32-10, NumPy-legacy
  * MT19937 with lazy per-word twist).
  *
- * Execution shape (CDNA4, wave64) — one env.step() is two dependent launches:
+ * Execution shape (CDNA4, wave64) — one env.step() is ONE launch in every Philox configuration (the
+ * ownship phase runs inside uam_sweep_kernel, one thread per env, and is handed over through LDS) and
+ * two dependent launches in the NumPy-compatible MT19937 mode:
  *   uam_own_kernel   one THREAD per env: the fp64 ownship kinematics, goal distance, env-level reward
  *                    tail and the ownship/goal part of the observation (coalesced over envs); result
- *                    handed over as a 48-byte record per env.  fp64 trig needs ~96 VGPRs; keeping it
- *                    out of the sweep lets that kernel run at 8 waves/SIMD.
+ *                    handed over as a 48-byte record per env (own_compute(): the same code is the
+ *                    fused phase).  fp64 trig needs ~96 VGPRs; the threads that run it fetch their
+ *                    quad afterwards, so the sweep still runs at 8 waves/SIMD.
  *   uam_sweep_kernel one env is owned by a sub-wave group of L = next_pow2(ceil(N/4)) lanes; a lane
  *                    owns a "quad" of 4 consecutive intruders, so every intruder field moves with
  *                    16-byte accesses and a wave touches 1 KiB of contiguous SoA per instruction.
  *                    The sequential semantics of the reference's intruder loop (NMAC early exit,
- *                    flags, respawn order) are recovered with two in-group shuffle reductions (min
+ *                    flags, respawn order) are recovered with two in-group DPP reductions (min
  *                    index of the first NMAC, packed sum of new conflicts) and a predicated commit.
  *                    Observations are staged in LDS per wave and streamed out 1 KiB per instruction.
+ *                    Template mode bits add the RandIntruder dynamics, the k-nearest observation and
+ *                    the nearest-intruder reward shaping of the HER env family.
  *   The ownship noise of the float32/Philox mode is drawn ahead for 16 steps by uam_noise_kernel.
  * Everything is compiled with -ffp-contract=off: the float32 sweep must not be
  * FMA-contracted and every fused operation is an explicit fma().
