@@ -470,7 +470,7 @@ def g6_randomenv(Config, N, seed, T):
     data["obs0"] = np.asarray(obs0)
     add_prefixed(data, "st0_", st0)
     data["actions"] = data["actions"].astype(np.int32)
-    save("g6_randomenv_n%d_seed%d" % (N, seed), dict(seed=seed, N=N, variant="SingleAircraftRandomEnv", obs_mode=0,
+    save("g6b_randomenv_n%d_seed%d" % (N, seed), dict(seed=seed, N=N, variant="SingleAircraftRandomEnv", obs_mode=0,
                                                      action_mode=0, dynamics=0, random_own_start=1), data)
 
 

@@ -10,7 +10,7 @@ TRAJECTORY_FIXTURES = [
     "g1_discrete9_n4_seed0", "g2_goalseek_n8_seed3", "g2_goalseek_n32_seed1", "g2_goalseek_n80_seed4",
     "g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal",
     "g8_continuous_n8_seed7", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
-    "g9b_mctsenv_n8_seed11", "g6_randomenv_n8_seed31",
+    "g9b_mctsenv_n8_seed11", "g6b_randomenv_n8_seed31",
 ]
 
 # SingleAircraftDiscrete9HEREnv (k-nearest observation, random ownship start, optional wall termination);
