@@ -14,6 +14,7 @@ from .envs import (BatchedSingleAircraftEnv, Config, LazyInfos, SingleAircraft2E
 from . import spaces
 from .sharded import ShardedSingleAircraftEnv, shard_bounds
 from .mcts import BatchedMCTS, mcts_config
+from .vec_env import UamVecEnv, HostInfos
 
 __all__ = [
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
@@ -21,4 +22,5 @@ __all__ = [
     "SingleAircraftDiscrete9HEREnv", "SingleAircraftDiscrete3HEREnv", "her_goal_reward", "her_input_reward",
     "make_config",
     "UamError", "build", "default_config", "spaces", "ShardedSingleAircraftEnv", "shard_bounds", "BatchedMCTS", "mcts_config",
+    "UamVecEnv", "HostInfos",
 ]

@@ -182,6 +182,16 @@ class BatchedSingleAircraftEnv:
         self._fixed_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._rew, self._done, self._info))
         self.closed = False
 
+    def bind_outputs(self, rew, done, info):
+        """Make `step` write rewards / dones / info codes into caller-owned device tensors (float32[B], uint8[B],
+        uint8[B]) — e.g. slices of one slab that leaves the device in a single copy."""
+        torch = self._torch
+        for t, dt in ((rew, torch.float32), (done, torch.uint8), (info, torch.uint8)):
+            if t.dtype != dt or t.numel() != self.num_envs or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("bind_outputs needs contiguous device tensors float32[B], uint8[B], uint8[B]")
+        self._rew, self._done, self._info = rew, done, info
+        self._fixed_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._rew, self._done, self._info))
+
     # ---- plumbing
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -297,11 +307,13 @@ class BatchedSingleAircraftEnv:
         capi.check(self._lib.uam_policy(self._h, {"random": 0, "goal": 1}[kind], int(seed), out.data_ptr(), self._stream()))
         return out
 
-    def episode_stats(self):
+    def episode_stats(self, ret=None, ln=None):
         """(return float64[B], length int32[B]) of each env's most recently finished episode (monitor=True)."""
         torch = self._torch
-        ret = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
-        ln = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
+        if ret is None:
+            ret = torch.empty((self.num_envs,), dtype=torch.float64, device=self.device)
+        if ln is None:
+            ln = torch.empty((self.num_envs,), dtype=torch.int32, device=self.device)
         capi.check(self._lib.uam_episode_stats(self._h, ret.data_ptr(), ln.data_ptr(), self._stream()))
         return ret, ln
 

@@ -512,3 +512,38 @@ def test_her_relabel_matches_reference_and_oracle(uamenv, oracle, sparse):
     assert np.array_equal(rew2.cpu().numpy(), want)
     g = uamenv.her_goal_reward(torch.from_numpy(big[:, :2].copy()).cuda(), torch.from_numpy(big[:, -2:].copy()).cuda(), sparse_reward=sparse)
     assert np.array_equal(g.cpu().numpy(), oracle.her_goal_reward(ocfg, big[:, :2], big[:, -2:]).astype(np.float32))
+
+
+# ---------------------------------------------------------------- NumPy-facing VecEnv adapter
+def test_numpy_vecenv_adapter_matches_device_path_and_monitor(uamenv):
+    """UamVecEnv = the baselines VecEnv contract with host arrays: same numbers as the device-tensor path on the same
+    seed and actions; dtypes as DummyVecEnv produces them; info['episode'] consistent with the rewards observed."""
+    B, N, T = 96, 8, 260
+    venv = uamenv.UamVecEnv(B, N, seed=5, monitor=True)
+    ref = uamenv.BatchedSingleAircraftEnv(B, N, seed=5, monitor=True)
+    assert venv.num_envs == B and venv.observation_space.shape == (4 * N + 8,) and venv.action_space.n == 9
+    o = venv.reset()
+    assert isinstance(o, np.ndarray) and o.dtype == np.float32 and o.shape == (B, 4 * N + 8)
+    assert np.array_equal(o, ref.reset().cpu().numpy())
+    rs = np.random.RandomState(0)
+    st = ref.get_state()
+    ret, ln, eps = np.zeros(B), np.zeros(B, dtype=np.int64), 0
+    for t in range(T):
+        acts = pu.goal_seek_actions(st, ref.cfg.d_heading, 0)
+        acts[rs.uniform(size=B) < 0.1] = rs.randint(0, 9)
+        venv.step_async(acts.astype(np.int64))                      # any integer dtype, like a Python learner would pass
+        obs, rew, done, infos = venv.step_wait()
+        o2, r2, d2, i2 = ref.step(acts)
+        assert obs.dtype == np.float32 and rew.dtype == np.float32 and done.dtype == np.bool_ and len(infos) == B
+        assert np.array_equal(obs, o2.cpu().numpy()) and np.array_equal(rew, r2.cpu().numpy())
+        assert np.array_equal(done, d2.cpu().numpy()) and np.array_equal(infos.codes, i2.codes.cpu().numpy())
+        ret += rew.astype(np.float64); ln += 1
+        for i, r, l in infos.episodes():
+            assert done[i] and abs(r - ret[i]) < 1e-9 and l == ln[i]
+            assert infos[i]["episode"]["l"] == l and infos[i]["result"] in ("g", "n")
+            eps += 1
+        ret[done] = 0.0; ln[done] = 0
+        st = ref.get_state()
+    assert eps > 0 and infos[0].keys() >= {"result"}
+    assert venv.get_images() == [] and venv.unwrapped is venv
+    venv.close(); ref.close()
