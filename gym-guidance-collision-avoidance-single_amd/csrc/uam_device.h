@@ -122,6 +122,8 @@ struct UamParams {
     uint8_t* done;
     uint8_t* info;
     const uint8_t* mask;
+    int32_t many_K;               /* uam_sweep_many_kernel: steps per launch; actions / reward / done / info / noise advance by */
+    int32_t act_step_words;       /* act_step_words 32-bit words resp. B elements per step */
     int32_t policy_kind;
     uint32_t policy_lo, policy_hi, policy_call;
     void* actions_out;
@@ -306,6 +308,13 @@ __device__ __forceinline__ void uam_philox_normals(uint32_t gid, uint32_t c_step
 }
 
 /* ------------------------------------------------------------------ small helpers */
+/* KC: the SGPR-pinned-constant flavour of the fp64 sincos (uam_pmath.h), bit-identical; used where the call sits
+ * inside a loop and the compiler would otherwise keep its ~60 literals in VGPRs across the whole loop */
+template <bool KC> __device__ __forceinline__ void sincos_sel(double x, double* sn, double* cs)
+{
+    if constexpr (KC) uam_sincos_k(x, sn, cs); else uam_sincos(x, sn, cs);
+}
+
 template <bool POS64> struct PosT { typedef float type; };
 template <> struct PosT<true> { typedef double type; };
 
@@ -412,7 +421,7 @@ __device__ __forceinline__ bool too_close(float ox, float oy, typename PosT<POS6
  * LEAN (float32 positions, Philox, speed/heading not held): the whole spawn is float32 arithmetic
  * on the Philox words — x, y, speed with 24 random bits, heading with 26 via the quadrant sincos —
  * so the sweep kernel carries no fp64 trig.  Otherwise the reference's float64 construction. */
-template <bool POS64, int RNG, bool LEAN>
+template <bool POS64, int RNG, bool LEAN, bool KC = false>
 __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_t idx, bool reset_phase, float ox,
                                       float oy, typename PosT<POS64>::type& X, typename PosT<POS64>::type& Y,
                                       bool& prom, float& vx, float& vy, double& sp, double& hd)
@@ -446,7 +455,7 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
         sp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
         hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
         double sn, cs;
-        uam_sincos(hd, &sn, &cs);
+        sincos_sel<KC>(hd, &sn, &cs);
         vx = (float)(sp * cs);
         vy = (float)(sp * sn);
         X = (P)(float)fx;
@@ -753,7 +762,7 @@ __device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int e
  * sequential, so the group walks i = 0..N-1 uniformly and the owner lane keeps
  * the result.  Stores the per-env fields (lane 0) and returns the obs tail.
  * ROS = SingleAircraftRandomEnv's random ownship start (needs fp64 trig here). */
-template <bool POS64, int RNG, bool SH, bool ROS>
+template <bool POS64, int RNG, bool SH, bool ROS, bool KC = false>
 __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, Rng<RNG>& rng,
                                  Quad<POS64, SH>& q, float* tail, float& rox, float& roy)
 {
@@ -782,7 +791,7 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
         osp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
         ohd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
         double sn, cs;
-        uam_sincos(ohd, &sn, &cs);
+        sincos_sel<KC>(ohd, &sn, &cs);
         ovx = (double)(float)(osp * cs); ovy = (double)(float)(osp * sn);
     }
     const float oxf = (float)ox, oyf = (float)oy;
@@ -793,14 +802,14 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
             const uint32_t idx = 4u * gl + j;
             if (quad_ok && idx < (uint32_t)p.N) {
                 typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
-                spawn_intruder<POS64, RNG, LEAN>(p, rng, idx, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
+                spawn_intruder<POS64, RNG, LEAN, KC>(p, rng, idx, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
                 q.set(j, X, Y, prom, vx, vy, sp, hd);
             }
         }
     } else {
         for (int i = 0; i < p.N; i++) {
             typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN, KC>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
             if ((i >> 2) == gl) q.set(i & 3, X, Y, prom, vx, vy, sp, hd);
         }
     }
@@ -824,8 +833,8 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
 /* ------------------------------------------------------------------ launch 1: ownship kernel
  * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
  * one thread per env. */
-template <int RNG>
-__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh)
+template <int RNG, bool KC = false>
+__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh, const int k = 0)
 {
     /* the cold configuration arrives BY VALUE (kernarg, scalar loads, no aliasing with the stores
      * below); every input is loaded up front so the thread pays one memory round trip, not five */
@@ -838,13 +847,13 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
      * unless the action is a pair), decoded after all loads are in flight */
     const bool is_pair = p.action_mode == UAM_ACT_PAIR;
     const uint32_t* __restrict__ aw = (const uint32_t*)p.actions;
-    const size_t i0 = is_pair ? 2 * (size_t)e : (size_t)e;
+    const size_t i0 = (is_pair ? 2 * (size_t)e : (size_t)e) + (size_t)k * (size_t)p.act_step_words;
     const uint32_t w0 = aw[i0], w1 = aw[is_pair ? i0 + 1 : i0];
     const int ai0 = (int)w0, ai1 = (int)w1;
     const float af = __uint_as_float(w0);
     double zh, zs;
     if constexpr (RNG == UAM_RNG_PHILOX) {
-        const double2 z = p.noise[e];   /* drawn ahead by uam_noise_kernel */
+        const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
         zh = z.x; zs = z.y;
     } else {
         Rng<UAM_RNG_MT19937> rng;
@@ -865,7 +874,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     sp = fmax(c.min_speed, fmin(sp, c.max_speed));
     sp += 0.0 + c.speed_sigma * zs;
     double sn, cs;
-    uam_sincos(hd, &sn, &cs);
+    sincos_sel<KC>(hd, &sn, &cs);
     const double vx = sp * cs, vy = sp * sn;
     ox = (float)((double)ox + vx);      /* float32 position += float64 velocity */
     oy = (float)((double)oy + vy);
@@ -919,13 +928,15 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
 #define UAM_MODE_RI 1
 #define UAM_MODE_SHAPED 2
 #define UAM_MODE_KNN 4
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED>
-__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
+/* one step of the sweep for this block.  k = step within the launch (0 for uam_sweep_kernel; the loop index of
+ * uam_sweep_many_kernel): the Philox step counter, the action / noise / reward / done / info rows advance with it;
+ * with_obs = this step emits the observation. */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED, bool KC = false>
+__device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, const bool with_obs)
 {
     typedef typename PosT<POS64>::type P;
     constexpr bool RI = (MODE & UAM_MODE_RI) != 0, SHAPED = (MODE & UAM_MODE_SHAPED) != 0, KNN = (MODE & UAM_MODE_KNN) != 0;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x;
     const int L = p.L;
     const int g = tid >> p.lshift, gl = tid & (L - 1);
@@ -949,7 +960,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
             const int e = blockIdx.x * p.E + tid;
             /* cold configuration through the pointer: its scalar loads (and SGPRs) stay inside this branch */
             const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();   /* see `pk` below */
-            if (e < p.B) own_compute<RNG>(pko, *pko.c, e, lds_share + 3 * tid);
+            if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k);
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();
@@ -1043,17 +1054,17 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
-        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
+        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN, KC>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true;
         }
     } else if (env_ok) {
-        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         for (;;) {
@@ -1062,7 +1073,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
             if (nxt == 0xFFFFu) break;
             if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN, KC>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             if (mine == nxt) {
                 resp &= ~(1u << (nxt & 3u));
                 q.set((int)(nxt & 3u), X, Y, prom, vx, vy, sp, hd);
@@ -1107,7 +1118,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
-            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
 #pragma unroll
             for (int m = 0; m < 2; m++) {          /* one Philox block per intruder pair */
                 const uint32_t pair = 2u * gl + m;
@@ -1121,7 +1132,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
                             const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * uam_u32d(w[2 * h + 1]);
                             q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
                             double sn, cs;
-                            uam_sincos(q.hd[SH ? j : 0], &sn, &cs);
+                            sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
                             q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
                             q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
                             vel_dirty = true;
@@ -1142,7 +1153,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
                             if ((i & 3) == j) {
                                 q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
                                 double sn, cs;
-                                uam_sincos(q.hd[SH ? j : 0], &sn, &cs);
+                                sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
                                 q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
                                 q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
                             }
@@ -1155,9 +1166,10 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 
     /* ---- per-env outputs (one lane per env) */
     if (env_ok && gl == 0) {
-        p.reward[env] = reward;
-        p.done[env] = done ? 1 : 0;
-        if (p.info) p.info[env] = (uint8_t)info;
+        const size_t orow = (size_t)k * (size_t)p.B + (size_t)env;
+        p.reward[orow] = reward;
+        p.done[orow] = done ? 1 : 0;
+        if (p.info) p.info[orow] = (uint8_t)info;
         if (!(done && p.auto_reset) && new_conf) p.s.no_conflict[env] += (int32_t)new_conf;
         if (p.track_ep) {   /* Monitor.step, baselines/bench/monitor.py:58-75 */
             const double r = p.s.ep_ret[env] + (double)reward;
@@ -1182,8 +1194,8 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
-        reset_env<POS64, RNG, SH, ROS>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
+        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
+        reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true;
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
@@ -1194,7 +1206,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
         if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
-    if (p.obs && !(UAM_ABLATE & 2)) {
+    if (with_obs && p.obs && !(UAM_ABLATE & 2)) {
         float* stage = (float*)(lds_raw + (FUSED ? (size_t)p.E * 48 : 0)) + (size_t)wave_first_g * p.D;
         if constexpr (KNN) {
             float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
@@ -1203,6 +1215,30 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
         } else {
             obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
         }
+    }
+}
+
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED>
+__global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    sweep_step<POS64, RNG, MODE, SH, ROS, FUSED>(p, lds_raw, 0, true);
+}
+
+/* K consecutive steps in ONE launch (uam_step_many, Philox): envs never interact and a block only ever touches
+ * its own E envs, so the block simply runs its envs' steps back to back — state through HBM/L2 as usual, one
+ * block barrier between steps (a reset writes the ownship from another wave than the one that reads it next).
+ * Removes K - 1 launches: small batches (4096 x 8, 8192 x 64) are launch-latency bound, not HBM bound.
+ * The observation is emitted by the last step only. */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+__global__ void UAM_STEP_BOUNDS uam_sweep_many_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int K = p.many_K;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, k == K - 1);
+        __syncthreads();
     }
 }
 

@@ -40,6 +40,8 @@ struct uam_env {
     int Np, Q, L, lshift, T, E, D, hold_sh;
     uint32_t step_index;        /* uam_step calls so far */
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
+    double2* noise_many;        /* [noise_many_cap][B] noise of one uam_step_many launch (grown on demand) */
+    int noise_many_cap;
     uint32_t noise_base;        /* step index of noise row 0 */
     bool noise_valid;
     std::vector<hipEvent_t> kev;  /* 3 events per sampled step (before own, between, after sweep) */
@@ -260,6 +262,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->ktiming = false;
     e->ksamples = 0;
     e->noise = nullptr;
+    e->noise_many = nullptr; e->noise_many_cap = 0;
     e->noise_base = 0;
     e->noise_valid = false;
     e->ev0 = nullptr; e->ev1 = nullptr;
@@ -438,6 +441,38 @@ static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
     else launch_sweep_ros<POS64, RNG, 0, false>(e, p, st);
 }
 
+/* K steps in one launch (float32 / Philox instances only; everything else loops over single steps) */
+template <int MODE, bool SH>
+static void launch_many_ros(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    dim3 grid(grid_of(e)), block(e->T);
+    const size_t lds = lds_stage(e, p) + (size_t)e->E * 48;
+    if (e->cfg.random_own_start)
+        hipLaunchKernelGGL((uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, true>), grid, block, lds, st, p);
+    else
+        hipLaunchKernelGGL((uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, false>), grid, block, lds, st, p);
+}
+
+static void launch_many(const uam_env* e, const UamParams& p, hipStream_t st)
+{
+    const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_many_ros<UAM_MODE_RI, true>(e, p, st);
+    else if (knn && e->cfg.shaped_reward) launch_many_ros<UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e, p, st);
+    else if (knn) launch_many_ros<UAM_MODE_KNN, false>(e, p, st);
+    else if (e->cfg.shaped_reward && !e->hold_sh) launch_many_ros<UAM_MODE_SHAPED, false>(e, p, st);
+    else if (e->hold_sh) launch_many_ros<0, true>(e, p, st);
+    else launch_many_ros<0, false>(e, p, st);
+}
+
+static bool many_supported(const uam_env* e)
+{
+    /* the looped kernel holds 115-166 VGPRs (3 waves/SIMD at worst = 3 of these 4-wave blocks per CU): it only pays
+     * while the whole grid is resident in one round — which is exactly the launch-bound small-batch regime */
+    const int resident_blocks = 256 * 3 * 256 / e->T;
+    return e->fused && e->cfg.precision == UAM_POS_F32 && !(e->cfg.shaped_reward && e->hold_sh) && !e->ktiming &&
+           grid_of(e) <= resident_blocks;
+}
+
 /* one env.step(): ownship kernel (thread per env) then the intruder sweep (lane group per env) */
 static const int KTIMING_MAX = 256;
 
@@ -557,6 +592,42 @@ extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, flo
     HIP_TRY(hipSetDevice(e->device));
     const size_t B = (size_t)e->cfg.num_envs;
     const size_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    if (K > 1 && many_supported(e)) {
+        /* one launch for all K steps (uam_sweep_many_kernel); the noise of exactly these steps is drawn first */
+        hipStream_t st = (hipStream_t)stream;
+        if (e->noise_many_cap < K) {
+            /* rare: grow the buffer.  Synchronous on purpose — the old buffer may still be read by a launch in
+             * flight, and dev_alloc's memset runs on the null stream */
+            HIP_TRY(hipDeviceSynchronize());
+            if (e->noise_many) {
+                for (auto it = e->allocs.begin(); it != e->allocs.end(); ++it)
+                    if (*it == (void*)e->noise_many) { e->allocs.erase(it); break; }
+                (void)hipFree(e->noise_many);
+                e->noise_many = nullptr; e->noise_many_cap = 0;
+            }
+            double2* nb = nullptr;
+            rc = dev_alloc(e, &nb, B * (size_t)K);
+            if (rc) return rc;
+            HIP_TRY(hipDeviceSynchronize());
+            e->noise_many = nb; e->noise_many_cap = K;
+        }
+        UamParams p;
+        fill_params(e, &p);
+        rc = check_obs_ptr(e, obs_out, &p);
+        if (rc) return rc;
+        const size_t total = (size_t)K * B;
+        hipLaunchKernelGGL(uam_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, e->noise_many,
+                           e->step_index, K);
+        p.noise = e->noise_many;
+        p.actions = action_tape; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
+        p.many_K = K;
+        p.act_step_words = (int32_t)(B * abytes / 4);
+        launch_many(e, p, st);
+        HIP_TRY(hipGetLastError());
+        e->step_index += (uint32_t)K;
+        if (e->timing) e->timed_launches++;
+        return UAM_OK;
+    }
     for (int k = 0; k < K; k++) {
         const void* a = (const char*)action_tape + (size_t)k * B * abytes;
         rc = step_once(e, a, k == K - 1 ? obs_out : nullptr, reward_out + (size_t)k * B, done_out + (size_t)k * B,

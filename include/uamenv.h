@@ -198,7 +198,13 @@ int uam_step(uam_env* env, const void* actions, float* obs_out, float* reward_ou
 
 /* K consecutive steps driven by an action tape [K, B(,2)] without host round
  * trips.  reward/done/info are [K, B]; obs_out (may be NULL) receives the
- * observation after the LAST step only.  Needs auto_reset = 1 to be useful. */
+ * observation after the LAST step only.  Needs auto_reset = 1 to be useful.
+ * Results are identical to K uam_step calls.  While the whole grid is resident
+ * in one round (small batches: the launch-latency-bound regime) and the handle
+ * is float32/Philox, all K steps run in ONE kernel launch (a block loops over
+ * its own envs' steps); otherwise K launches are queued back to back.  This is
+ * the open-loop form of the reference's agent loops, which hold a planned
+ * action for update_frame = 5 steps (Algorithms/MCTS/Agent.py:33-45). */
 int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_out,
                   float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
 

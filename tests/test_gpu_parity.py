@@ -547,3 +547,30 @@ def test_numpy_vecenv_adapter_matches_device_path_and_monitor(uamenv):
     assert eps > 0 and infos[0].keys() >= {"result"}
     assert venv.get_images() == [] and venv.unwrapped is venv
     venv.close(); ref.close()
+
+
+# ---------------------------------------------------------------- uam_step_many: K steps in one launch
+@pytest.mark.parametrize("variant,B,N,K", [("discrete9", 4096, 8, 7), ("discrete9", 300, 32, 16), ("randintruder", 512, 64, 5),
+                                           ("her9", 700, 20, 9), ("her3", 257, 8, 12), ("random_start", 1000, 4, 33),
+                                           ("continuous", 640, 32, 3), ("discrete9", 65536, 32, 4)])
+def test_step_many_single_launch_equals_single_steps(uamenv, variant, B, N, K):
+    """The looped kernel (small grids) and the loop of launches (large grids, last case) must both reproduce K
+    separate uam_step calls bit for bit: rewards, dones, infos, the final observation and the whole state."""
+    import torch
+    a = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=11, monitor=True)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=11, monitor=True)
+    a.reset(); b.reset()
+    for rep in range(3):
+        tape = torch.stack([a.policy_actions("goal" if rep else "random", seed=rep * 100 + k) for k in range(K)])
+        obs_m, rew_m, done_m, info_m = a.step_many(tape)
+        for k in range(K):
+            o, r, d, i = b.step(tape[k])
+            assert torch.equal(rew_m[k], r) and torch.equal(done_m[k], d.view(torch.uint8)) and torch.equal(info_m[k], i.codes), (rep, k)
+        assert torch.equal(obs_m, o)
+        pu.compare_states(a.get_state(), b.get_state(), "after step_many rep %d" % rep,
+                          hold_sh=variant == "randintruder")
+        ra, la = a.episode_stats(); rb, lb = b.episode_stats()
+        assert torch.equal(ra, rb) and torch.equal(la, lb)
+    if variant == "her3":
+        assert torch.equal(a.nearest(), b.nearest())
+    a.close(); b.close()
