@@ -400,6 +400,27 @@ class SingleAircraftEnv:
         self.window_width, self.window_height = config.window_width, config.window_height
         self.viewer = None
         self.state = None
+        # one step = one launch sequence + ONE host synchronisation: reward, done, info and no_conflict live in a
+        # 16-byte device slab next to the observation row, and both leave through page-locked buffers
+        torch = self._vec._torch
+        v = self._vec
+        self._d_slab = torch.zeros((16,), dtype=torch.uint8, device=v.device)
+        self._h_slab = torch.zeros((16,), dtype=torch.uint8, pin_memory=True)
+        self._h_obs = torch.zeros((1, v.obs_dim), dtype=torch.float32, pin_memory=True)
+        v.bind_outputs(self._d_slab[0:4].view(torch.float32), self._d_slab[4:5], self._d_slab[5:6])
+        self._d_nc = self._d_slab[8:12].view(torch.int32)
+        self._no_conflict = 0
+
+    def _fetch(self, obs):
+        """Bring the observation row and the scalar slab to the host with one synchronisation."""
+        v = self._vec
+        capi.check(v._lib.uam_counters(v._h, self._d_nc.data_ptr(), v._stream()))
+        self._h_obs.copy_(obs, non_blocking=True)
+        self._h_slab.copy_(self._d_slab, non_blocking=True)
+        v._torch.cuda.current_stream(v.device).synchronize()
+        h = self._h_slab.numpy()
+        self._no_conflict = int(h[8:12].view(np.int32)[0])
+        return float(h[0:4].view(np.float32)[0]), bool(h[4]), int(h[5])
 
     def seed(self, seed=None):
         """Unlike the reference (whose per-env np_random is never used, :43-45) this really seeds the env:
@@ -409,22 +430,29 @@ class SingleAircraftEnv:
         return [seed]
 
     def _obs_np(self, t):
-        return t[0].cpu().numpy().astype(np.float64)
+        return t[0].numpy().astype(np.float64)
 
     def reset(self):
-        return self._obs_np(self._vec.reset())
+        self._fetch(self._vec.reset())
+        return self._obs_np(self._h_obs)
 
     def _encode_action(self, action):
         return [int(action)]
 
+    def _step_host(self, action):
+        obs, _, _, _ = self._vec.step(self._encode_action(action))
+        rew, done, code = self._fetch(obs)
+        return self._obs_np(self._h_obs), rew, done, code
+
     def step(self, action):
-        obs, rew, done, infos = self._vec.step(self._encode_action(action))
-        return self._obs_np(obs), float(rew[0].item()), bool(done[0].item()), \
-            LazyInfos(infos.codes, self._info_as_dict)[0]
+        ob, rew, done, code = self._step_host(action)
+        info = capi.INFO_CODES[code]
+        return ob, rew, done, ({"result": info} if self._info_as_dict else info)
 
     @property
     def no_conflict(self):
-        return int(self._vec.no_conflict[0].item())
+        """Agent.py:61 reads env.no_conflict after the episode: the counter as of the last reset()/step()."""
+        return self._no_conflict
 
     def render(self, mode="human"):
         return None   # no display on the GPU box; SURVEY §2 #8 (out of scope)
@@ -484,7 +512,7 @@ class SingleAircraftDiscrete9HEREnv(SingleAircraftEnv):
         return out
 
     def _obs_np(self, t):
-        row = t[0].cpu().numpy().astype(np.float64)
+        row = t[0].numpy().astype(np.float64)
         k = 4 + 5 * int(self._vec.cfg.knn)
         return {"observation": row[:k], "achieved_goal": row[k:k + 2], "desired_goal": row[k + 2:k + 4]}
 
@@ -521,9 +549,17 @@ class SingleAircraftDiscrete3HEREnv(SingleAircraftDiscrete9HEREnv):
     step reward shaped by the nearest intruder; step() returns that distance in place of the info dict (:178)."""
     _variant = "her3"
 
+    def _fetch(self, obs):
+        v = self._vec
+        if v.cfg.shaped_reward:      # the nearest-intruder distance rides in the same slab (bytes 12..15)
+            capi.check(v._lib.uam_nearest(v._h, self._d_slab[12:16].view(v._torch.float32).data_ptr(), v._stream()))
+        out = super()._fetch(obs)
+        self._nearest = float(self._h_slab.numpy()[12:16].view(np.float32)[0])
+        return out
+
     def step(self, action):
-        obs, rew, done, _ = self._vec.step([int(action)])
-        return self._obs_np(obs), float(rew[0].item()), bool(done[0].item()), float(self._vec.nearest()[0].item())
+        ob, rew, done, _ = self._step_host(action)
+        return ob, rew, done, self._nearest
 
 
 def _her_cfg(config, sparse_reward, knn, num_intruders):
