@@ -1222,7 +1222,10 @@ template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    sweep_step<POS64, RNG, MODE, SH, ROS, FUSED>(p, lds_raw, 0, true);
+    /* exact-promotion Philox instances: the fp64 spawn sits inside the respawn loop, and the SGPR-pinned sincos
+     * flavour keeps its literals out of the VGPRs held across that loop (131 -> 91 VGPRs, -6 % step time).  The
+     * RandIntruder and MT19937 instances measure slower with it (+3...16 %) and keep the plain flavour. */
+    sweep_step<POS64, RNG, MODE, SH, ROS, FUSED, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, true);
 }
 
 /* K consecutive steps in ONE launch (uam_step_many, Philox): envs never interact and a block only ever touches
