@@ -30,6 +30,7 @@
 #include "uam_device.h"
 
 #define UAM_MCTS_MAX_NODES 256          /* simulations + 1 <= 256 (node ids are bytes) */
+#define UAM_MCTS_SMALL_NODES 128        /* tree capacity of the small instances (simulations <= 126) */
 #define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
 #define UAM_MCTS_WAVES_PER_BLOCK 2
 #ifndef UAM_MCTS_WAVES_PER_EU
@@ -60,12 +61,11 @@ struct UamMctsParams {
     double* reward_out;                  /* [B] */
 };
 
-/* tree bookkeeping of one root (one wave) in LDS */
-struct MctsTree {
-    double n[UAM_MCTS_MAX_NODES], q[UAM_MCTS_MAX_NODES], rew[UAM_MCTS_MAX_NODES];
-    uint8_t parent[UAM_MCTS_MAX_NODES], nchild[UAM_MCTS_MAX_NODES], depth[UAM_MCTS_MAX_NODES],
-        term[UAM_MCTS_MAX_NODES], act[UAM_MCTS_MAX_NODES];
-    uint8_t child[UAM_MCTS_MAX_NODES][9];
+/* tree bookkeeping of one root (one wave) in LDS: 38 B per node */
+template <int CAP> struct MctsTree {
+    double n[CAP], q[CAP], rew[CAP];
+    uint8_t parent[CAP], nchild[CAP], depth[CAP], term[CAP], act[CAP];
+    uint8_t child[CAP][9];
 };
 
 /* the state vector of one node, distributed over the wave (K intruders per lane) */
@@ -369,16 +369,12 @@ __device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const dou
 }
 
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
-template <int K, int MODEL>
-__global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
+template <int K, int MODEL, int CAP>
+__device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP>& t, double* const qbuf)
 {
-    __shared__ MctsTree trees[UAM_MCTS_WAVES_PER_BLOCK];
-    __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
     if (root >= p.B) return;
-    MctsTree& t = trees[wv];
-    double* const qbuf = queues[wv];
     double* pint = p.pool_int + (size_t)root * p.cap * 5 * p.Npad;
     double* pown = p.pool_own + (size_t)root * p.cap * 8;
 
@@ -494,6 +490,27 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
             if (p.child_n_out) p.child_n_out[9 * (size_t)root + lane] = has ? t.n[c] : 0.0;
         }
     }
+}
+
+/* Two launch flavours of the same search.  The kernel is bound by the latency of its fp64 dependency chains, so
+ * residency matters more than spill-free registers: with a 128-node tree (simulations <= 126, the shipped 100)
+ * and one intruder per lane the LDS footprint allows 4 waves/SIMD, and capping the registers there (128 VGPRs,
+ * 68 B of scratch) measures 8 % faster than 3 waves at 147 VGPRs; 5 waves (96 VGPRs, 196 B scratch) is slower. */
+template <int K, int MODEL>
+__global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
+{
+    __shared__ MctsTree<UAM_MCTS_MAX_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
+    __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
+    mcts_search<K, MODEL, UAM_MCTS_MAX_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6]);
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+uam_mcts_search_small_kernel(const UamMctsParams p)
+{
+    __shared__ MctsTree<UAM_MCTS_SMALL_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
+    __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(1)];
+    mcts_search<1, MODEL, UAM_MCTS_SMALL_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6]);
 }
 
 /* one move() per state, no tree: parity / building block */

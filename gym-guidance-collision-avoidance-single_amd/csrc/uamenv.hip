@@ -1129,7 +1129,14 @@ extern "C" int uam_mcts_best_action(const uam_mcts_config* c, int device_id, con
         default: hipLaunchKernelGGL((KERNEL<4, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;  \
         }                                                                                                  \
     }
-    UAM_MCTS_LAUNCH(uam_mcts_search_kernel)
+    if (p.K == 1 && p.cap <= UAM_MCTS_SMALL_NODES - 1) {      /* node ids < 127: the 4-waves/SIMD flavour */
+        if (c->model == UAM_MCTS_MODEL_STRAIGHT4)
+            hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p);
+    } else {
+        UAM_MCTS_LAUNCH(uam_mcts_search_kernel)
+    }
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }
