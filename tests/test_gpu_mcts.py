@@ -180,3 +180,17 @@ def test_agent_loop_on_mcts_env(uamenv):
         assert bool(((acts >= 0) & (acts <= 2)).all())
         env.step(acts)
     env.close()
+
+
+def test_planner_avoids_collisions_end_to_end(uamenv):
+    """The Agent_RandInt.py experiment in small: planning with the batched MCTS must cut the NMAC rate of the
+    goal-seeking heuristic by a wide margin on the same seeds (functional check of the whole planner stack)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("mcts_agent", os.path.join(os.path.dirname(__file__), "..", "examples", "mcts_agent.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    planned = mod.run("mcts", 512, 20, 600, 100, 3, seed=3)
+    greedy = mod.run("goal", 512, 20, 600, 100, 3, seed=3)
+    assert planned["episodes"] > 500 and greedy["episodes"] > 500
+    assert greedy["nmac_prob"] > 0.05 and planned["nmac_prob"] < 0.25 * greedy["nmac_prob"], (planned, greedy)
+    assert planned["goal_prob"] > 0.95
