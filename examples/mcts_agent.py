@@ -13,9 +13,12 @@ import torch
 import uamenv
 
 
-def run(policy, B, N, steps, sims, depth, seed, update_frame=5):
-    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=seed, monitor=True)
-    planner = uamenv.BatchedMCTS(N, seed=seed, simulations=sims, search_depth=depth) if policy == "mcts" else None
+def run(policy, B, N, steps, sims, depth, seed, update_frame=5, agent="agent_randint"):
+    # agent_randint: Agent_RandInt.py = RandIntruder env + nodes_single_randintru.py (6-wide state);
+    # agent: Agent.py = SingleAircraftMCTSEnv + nodes_single.py (4-wide state, upstream quirks included)
+    variant, model = ("randintruder", "randintru") if agent == "agent_randint" else ("mcts", "straight4")
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=seed, monitor=True)
+    planner = uamenv.BatchedMCTS(N, seed=seed, simulations=sims, search_depth=depth, model=model) if policy == "mcts" else None
     env.reset()
     counts = torch.zeros(5, dtype=torch.int64, device=env.device)        # info codes of finished episodes
     conflicts = torch.zeros((), dtype=torch.int64, device=env.device)    # env.no_conflict summed over finished episodes
@@ -43,7 +46,7 @@ def run(policy, B, N, steps, sims, depth, seed, update_frame=5):
     wall = time.perf_counter() - t0
     episodes = int(counts.sum().item())
     c = counts.cpu().tolist()
-    return {"policy": policy, "envs": B, "intruders": N, "steps": steps, "episodes": episodes,
+    return {"agent": agent, "policy": policy, "envs": B, "intruders": N, "steps": steps, "episodes": episodes,
             "nmac_prob": round(c[3] / max(1, episodes), 4), "goal_prob": round(c[2] / max(1, episodes), 4),
             "avg_conflicts_per_episode": round(float(conflicts.item()) / max(1, episodes), 3),
             "env_steps_per_s": round(B * steps / wall), "wall_s": round(wall, 2)}
@@ -58,6 +61,7 @@ if __name__ == "__main__":
     ap.add_argument("--search_depth", "-d", type=int, default=3)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--policies", default="mcts,goal,random")
+    ap.add_argument("--agent", default="agent_randint", choices=["agent_randint", "agent"])
     a = ap.parse_args()
     for pol in a.policies.split(","):
-        print(json.dumps(run(pol, a.envs, a.intruders, a.steps, a.no_simulations, a.search_depth, a.seed)))
+        print(json.dumps(run(pol, a.envs, a.intruders, a.steps, a.no_simulations, a.search_depth, a.seed, agent=a.agent)))
