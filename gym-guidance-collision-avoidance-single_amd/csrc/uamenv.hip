@@ -1061,7 +1061,8 @@ static int mcts_validate(const uam_mcts_config* c, int32_t B)
     /* node ids are bytes and 255 is the "no parent" sentinel: at most 255 nodes (root + one per simulation) */
     if (c->simulations < 1 || c->simulations + 1 > UAM_MCTS_MAX_NODES - 1)
         return fail(UAM_EINVAL, "simulations must be in 1..%d (got %d)", UAM_MCTS_MAX_NODES - 2, c->simulations);
-    if (c->search_depth < 0 || c->search_depth > 14) return fail(UAM_EINVAL, "search_depth must be in 0..14 (Philox move field)");
+    /* depth 0 makes the root terminal: the reference then calls np.argmax([]) in best_child (common.py:52) and raises */
+    if (c->search_depth < 1 || c->search_depth > 14) return fail(UAM_EINVAL, "search_depth must be in 1..14 (got %d)", c->search_depth);
     if (c->simulate_frame < 1 || c->simulate_frame > 64)
         return fail(UAM_EINVAL, "simulate_frame must be in 1..64 (one lane per frame of a move; got %d)", c->simulate_frame);
     if (B < 1) return fail(UAM_EINVAL, "need at least one root (got %d)", B);

@@ -78,6 +78,8 @@ def test_bad_mcts_config_is_rejected(uamenv):
         uamenv.BatchedMCTS(8, simulations=255).best_action(np.zeros((1, 56)))
     with pytest.raises(uamenv.UamError):
         uamenv.BatchedMCTS(300).best_action(np.zeros((1, 6 * 300 + 8)))
+    with pytest.raises(uamenv.UamError):      # the reference raises too: np.argmax([]) on a terminal root
+        uamenv.BatchedMCTS(8, search_depth=0).best_action(np.zeros((1, 56)))
     with pytest.raises(ValueError):
         uamenv.BatchedMCTS(8).best_action(np.zeros((1, 40)))
 
