@@ -88,3 +88,38 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(txt), "%s references the oracle" % os.path.join(dirpath, f)
+
+
+def test_variant_configs_follow_the_reference_classes(capi):
+    """Host logic (no GPU): every variant name maps to the obs/action/dynamics combination of its reference class."""
+    import uamenv
+    want = {  # variant: (obs_mode, action_mode, dynamics, random_own_start, obs_dim at N=8)
+        "discrete9": (0, 0, 0, 0, 40), "continuous": (0, 2, 0, 0, 40), "mcts": (1, 1, 0, 0, 40),
+        "randintruder": (2, 1, 1, 0, 56), "random_start": (0, 0, 0, 1, 40), "her9": (3, 0, 0, 1, 28), "her3": (3, 3, 0, 1, 28),
+    }
+    for variant, (om, am, dyn, ros, D) in want.items():
+        cfg = uamenv.make_config(16, 8, variant=variant)
+        assert (cfg.obs_mode, cfg.action_mode, cfg.dynamics, cfg.random_own_start) == (om, am, dyn, ros), variant
+        assert capi.obs_dim(cfg) == D, variant
+    her3 = uamenv.make_config(4, 8, variant="her3")
+    assert her3.shaped_reward == 1 and her3.goal_margin == 100.0 and her3.conflict_coeff == 0.00025 and her3.knn == 4
+    assert uamenv.make_config(4, 8, variant="her9").shaped_reward == 0
+
+    class Sparse(uamenv.Config):
+        sparse_reward = True
+    assert uamenv.make_config(4, 8, variant="her9", config=Sparse).wall_terminates == 1      # Discrete9HEREnv.py:217-221
+    assert uamenv.make_config(4, 8, variant="discrete9", config=Sparse).wall_terminates == 0
+    with pytest.raises(AttributeError):
+        uamenv.make_config(4, 8, no_such_field=1)
+
+
+def test_host_infos_sequences(capi):
+    """LazyInfos / HostInfos rebuild the reference's info objects from code arrays (host logic, no GPU)."""
+    import uamenv
+    codes = np.array([0, 1, 2, 3, 4], dtype=np.uint8)
+    done = np.array([False, False, True, True, True])
+    h = uamenv.HostInfos(codes, done, np.array([0.0, 0.0, 1.5, -1.0, -0.5]), np.array([0, 0, 120, 7, 33], dtype=np.int32), 12.5)
+    assert [i["result"] for i in h] == ["", "c", "g", "n", "w"] and len(h) == 5
+    assert "episode" not in h[0] and h[2]["episode"] == {"r": 1.5, "l": 120, "t": 12.5}
+    assert h.episodes() == [(2, 1.5, 120), (3, -1.0, 7), (4, -0.5, 33)]
+    assert uamenv.HostInfos(codes, done, None, None, 0.0).episodes() == []
