@@ -454,10 +454,17 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
         double fx = 0.0 + p.c->W * u[0], fy = 0.0 + p.c->H * u[1];
         sp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
         hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
-        double sn, cs;
-        sincos_sel<KC>(hd, &sn, &cs);
-        vx = (float)(sp * cs);
-        vy = (float)(sp * sn);
+        if constexpr (!POS64 && RNG == UAM_RNG_PHILOX) {
+            float sn, cs;                                /* float32 Philox mode: no fp64 trig (uam_pmath.h) */
+            uam_sincos_heading_f32(hd, &sn, &cs);
+            vx = (float)(sp * (double)cs);
+            vy = (float)(sp * (double)sn);
+        } else {
+            double sn, cs;
+            sincos_sel<KC>(hd, &sn, &cs);
+            vx = (float)(sp * cs);
+            vy = (float)(sp * sn);
+        }
         X = (P)(float)fx;
         Y = (P)(float)fy;
         prom = false;
@@ -1131,10 +1138,17 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
                         if (4u * gl + j < (uint32_t)p.N && uam_u32d(w[2 * h]) < p.c->hc_prob) {
                             const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * uam_u32d(w[2 * h + 1]);
                             q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
-                            double sn, cs;
-                            sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
-                            q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
-                            q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
+                            if constexpr (!POS64) {
+                                float sn, cs;            /* float32 Philox mode: no fp64 trig (uam_pmath.h) */
+                                uam_sincos_heading_f32(q.hd[SH ? j : 0], &sn, &cs);
+                                q.vx[j] = (float)(q.sp[SH ? j : 0] * (double)cs);
+                                q.vy[j] = (float)(q.sp[SH ? j : 0] * (double)sn);
+                            } else {
+                                double sn, cs;
+                                sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
+                                q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
+                                q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
+                            }
                             vel_dirty = true;
                         }
                     }

@@ -88,4 +88,18 @@ UAM_HD void uam_sincos_turn_f32(uint32_t w, float* sn, float* cs)
     *cs = rc;
 }
 
+/* float32 sin and cos of a float64 heading (any magnitude): the heading is reduced to a fraction of a turn in
+ * float64 (multiply, floor, subtract: exact IEEE operations, identical on host and device) and the top 26 bits of
+ * that fraction go through uam_sincos_turn_f32.  Angular resolution 2*pi/2^26 = 9.4e-8 rad.  Used for the
+ * float32 velocities derived from held headings in the float32 Philox mode (RandIntruder heading changes,
+ * spawns of envs that hold speed/heading): keeps fp64 trig out of those sweep instances. */
+UAM_HD void uam_sincos_heading_f32(double heading, float* sn, float* cs)
+{
+    double t = heading * 0x1.45f306dc9c883p-3;      /* 1 / (2 pi) */
+    t = t - __builtin_floor(t);
+    const double s = t * 4294967296.0;
+    const uint32_t w = s >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)s;
+    uam_sincos_turn_f32(w, sn, cs);
+}
+
 #endif /* UAM_PMATH_H */

@@ -275,7 +275,15 @@ static void spawn_intruder(const ctx_t* c, int idx, int reset_phase, intruder_t*
         heading = 0.0 + (2.0 * M_PI - 0.0) * u32d(w[3]);
     }
     double sn, cs;
-    m_sincos(b, heading, &sn, &cs);
+    if (g->rng_mode == UAM_RNG_PHILOX && g->precision == UAM_POS_F32) {
+        /* float32 Philox mode: the float32 velocity comes from the float32 sincos of the heading's turn fraction
+         * (no fp64 trig in the product's float32 sweeps) */
+        float sn32, cs32;
+        uam_sincos_heading_f32(heading, &sn32, &cs32);
+        sn = (double)sn32; cs = (double)cs32;
+    } else {
+        m_sincos(b, heading, &sn, &cs);
+    }
     out->x = (double)(float)px;           /* np.array(position, dtype=np.float32), :272 */
     out->y = (double)(float)py;
     out->promoted = 0;
@@ -588,7 +596,13 @@ static void update_headings(const ctx_t* c)
             intruder_t* it = &e->in[i];
             it->heading = it->heading + delta;
             double sn, cs;
-            m_sincos(b, it->heading, &sn, &cs);
+            if (g->rng_mode == UAM_RNG_PHILOX && g->precision == UAM_POS_F32) {     /* as in spawn_intruder */
+                float sn32, cs32;
+                uam_sincos_heading_f32(it->heading, &sn32, &cs32);
+                sn = (double)sn32; cs = (double)cs32;
+            } else {
+                m_sincos(b, it->heading, &sn, &cs);
+            }
             it->vx = (float)(it->speed * cs);
             it->vy = (float)(it->speed * sn);
         }
