@@ -113,6 +113,7 @@ struct UamParams {
     float nmac_pen32, conf_pen32;
     float near_thr32, near_coeff32;      /* float32(3 * minimum_separation), float32(conflict_coeff) */
     float inv_diag32;                    /* 1 / float32(Config.diagonal) */
+    unsigned long long hc_thr;           /* ceil(hc_prob * 2^32): word * 2^-32 < hc_prob  <=>  word < hc_thr */
     float spawn_sx, spawn_sy, min_speed32, vrange32;   /* float32 spawn (lean Philox mode) */
     const double2* noise;         /* [B] (zh, zs) of this step, produced ahead by uam_noise_kernel (Philox) */
     /* per-call I/O (device pointers owned by the caller) */
@@ -1126,31 +1127,29 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
             rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+            /* one Philox block per quad: word j is intruder j's Bernoulli uniform u; a change takes its second
+             * uniform as u / hc_prob (uniform on [0,1) given u < hc_prob) */
+            if (quad_ok) {
+                uint32_t w[4];
+                rng.block(false, UAM_PH_HEADCHG, (uint32_t)gl, 0, w);
 #pragma unroll
-            for (int m = 0; m < 2; m++) {          /* one Philox block per intruder pair */
-                const uint32_t pair = 2u * gl + m;
-                if (quad_ok && 2u * pair < (uint32_t)p.N) {
-                    uint32_t w[4];
-                    rng.block(false, UAM_PH_HEADCHG, pair, 0, w);
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int j = 2 * m + h;
-                        if (4u * gl + j < (uint32_t)p.N && uam_u32d(w[2 * h]) < p.c->hc_prob) {
-                            const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * uam_u32d(w[2 * h + 1]);
-                            q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
-                            if constexpr (!POS64) {
-                                float sn, cs;            /* float32 Philox mode: no fp64 trig (uam_pmath.h) */
-                                uam_sincos_heading_f32(q.hd[SH ? j : 0], &sn, &cs);
-                                q.vx[j] = (float)(q.sp[SH ? j : 0] * (double)cs);
-                                q.vy[j] = (float)(q.sp[SH ? j : 0] * (double)sn);
-                            } else {
-                                double sn, cs;
-                                sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
-                                q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
-                                q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
-                            }
-                            vel_dirty = true;
+                for (int j = 0; j < 4; j++) {
+                    if (4u * gl + j < (uint32_t)p.N && (unsigned long long)w[j] < p.hc_thr) {
+                        const double ud = uam_u32d(w[j]) / p.c->hc_prob;
+                        const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * ud;
+                        q.hd[SH ? j : 0] = q.hd[SH ? j : 0] + deg * UAM_DEG2RAD;
+                        if constexpr (!POS64) {
+                            float sn, cs;            /* float32 Philox mode: no fp64 trig (uam_pmath.h) */
+                            uam_sincos_heading_f32(q.hd[SH ? j : 0], &sn, &cs);
+                            q.vx[j] = (float)(q.sp[SH ? j : 0] * (double)cs);
+                            q.vy[j] = (float)(q.sp[SH ? j : 0] * (double)sn);
+                        } else {
+                            double sn, cs;
+                            sincos_sel<KC>(q.hd[SH ? j : 0], &sn, &cs);
+                            q.vx[j] = (float)(q.sp[SH ? j : 0] * cs);
+                            q.vy[j] = (float)(q.sp[SH ? j : 0] * sn);
                         }
+                        vel_dirty = true;
                     }
                 }
             }

@@ -217,6 +217,10 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->shaped = c.shaped_reward ? 1 : 0;
     p->near_thr32 = (float)(3 * c.minimum_separation); p->near_coeff32 = (float)c.conflict_coeff;
     p->inv_diag32 = c.diagonal > 0 ? 1.0f / (float)c.diagonal : 0.f;
+    {   /* word * 2^-32 < prob  <=>  word < ceil(prob * 2^32) (scaling by 2^32 is exact) */
+        const double t = c.heading_change_prob * 4294967296.0;
+        p->hc_thr = t <= 0.0 ? 0ull : (t >= 4294967296.0 ? 4294967296ull : (unsigned long long)ceil(t));
+    }
     p->obs_w = c.obs_mode == UAM_OBS_RAW6 ? 6 : 4;
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;

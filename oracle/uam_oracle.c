@@ -584,11 +584,12 @@ static void update_headings(const ctx_t* c)
             take = p < g->heading_change_prob;
             ud = take ? mt_double(e->mt) : 0.0;
         } else {
-            uint32_t w[4];   /* one call serves the intruder pair (2m, 2m+1) */
-            philox(c, PH_HEADCHG, (uint32_t)(i >> 1), 0, w);
-            p = u32d(w[2 * (i & 1)]);
+            uint32_t w[4];   /* one call serves the intruder quad 4m..4m+3: word i&3 is the Bernoulli uniform; a change
+                              * takes its second uniform as p / heading_change_prob (uniform given p < prob) */
+            philox(c, PH_HEADCHG, (uint32_t)(i >> 2), 0, w);
+            p = u32d(w[i & 3]);
             take = p < g->heading_change_prob;
-            ud = u32d(w[2 * (i & 1) + 1]);
+            ud = take ? p / g->heading_change_prob : 0.0;
         }
         if (take) {
             double deg = -g->heading_change_max_deg + (g->heading_change_max_deg - (-g->heading_change_max_deg)) * ud;
