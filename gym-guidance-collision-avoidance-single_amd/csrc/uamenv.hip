@@ -667,7 +667,7 @@ extern "C" int uam_nearest(uam_env* e, float* nearest_out_dev, void* stream)
     if (!e || !nearest_out_dev) return fail(UAM_EINVAL, "NULL argument");
     if (!e->cfg.shaped_reward) return fail(UAM_EINVAL, "the nearest-intruder distance is only tracked with uam_config.shaped_reward = 1");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(nearest_out_dev, e->s.nearest, (size_t)e->cfg.num_envs * 4, hipMemcpyDeviceToDevice,
+    HIP_TRY(hipMemcpyAsync(nearest_out_dev, e->s.nearest, (size_t)e->cfg.num_envs * 4, hipMemcpyDefault,
                            (hipStream_t)stream));
     return UAM_OK;
 }
@@ -728,7 +728,7 @@ extern "C" int uam_counters(uam_env* e, int32_t* no_conflict_out_dev, void* stre
 {
     if (!e || !no_conflict_out_dev) return fail(UAM_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemcpyAsync(no_conflict_out_dev, e->s.no_conflict, (size_t)e->cfg.num_envs * 4, hipMemcpyDeviceToDevice,
+    HIP_TRY(hipMemcpyAsync(no_conflict_out_dev, e->s.no_conflict, (size_t)e->cfg.num_envs * 4, hipMemcpyDefault,
                            (hipStream_t)stream));
     return UAM_OK;
 }

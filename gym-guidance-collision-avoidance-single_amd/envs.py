@@ -182,13 +182,19 @@ class BatchedSingleAircraftEnv:
         self._fixed_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._rew, self._done, self._info))
         self.closed = False
 
-    def bind_outputs(self, rew, done, info):
-        """Make `step` write rewards / dones / info codes into caller-owned device tensors (float32[B], uint8[B],
-        uint8[B]) — e.g. slices of one slab that leaves the device in a single copy."""
+    def bind_outputs(self, rew, done, info, obs=None):
+        """Make `step` write rewards / dones / info codes (and optionally the observations) into caller-owned device
+        tensors (float32[B], uint8[B], uint8[B], float32[B, D]) — e.g. slices of one slab that leaves the device in
+        a single copy."""
         torch = self._torch
         for t, dt in ((rew, torch.float32), (done, torch.uint8), (info, torch.uint8)):
             if t.dtype != dt or t.numel() != self.num_envs or not t.is_contiguous() or t.device != self.device:
                 raise ValueError("bind_outputs needs contiguous device tensors float32[B], uint8[B], uint8[B]")
+        if obs is not None:
+            if obs.dtype != torch.float32 or tuple(obs.shape) != (self.num_envs, self.obs_dim) or not obs.is_contiguous() \
+                    or obs.device != self.device:
+                raise ValueError("bind_outputs: obs must be a contiguous device tensor float32[B, D]")
+            self._obs = obs
         self._rew, self._done, self._info = rew, done, info
         self._fixed_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._rew, self._done, self._info))
 
@@ -404,22 +410,31 @@ class SingleAircraftEnv:
         # 16-byte device slab next to the observation row, and both leave through page-locked buffers
         torch = self._vec._torch
         v = self._vec
-        self._d_slab = torch.zeros((16,), dtype=torch.uint8, device=v.device)
-        self._h_slab = torch.zeros((16,), dtype=torch.uint8, pin_memory=True)
-        self._h_obs = torch.zeros((1, v.obs_dim), dtype=torch.float32, pin_memory=True)
-        v.bind_outputs(self._d_slab[0:4].view(torch.float32), self._d_slab[4:5], self._d_slab[5:6])
-        self._d_nc = self._d_slab[8:12].view(torch.int32)
+        nb = 4 * v.obs_dim
+        self._d_slab = torch.zeros((nb + 16,), dtype=torch.uint8, device=v.device)      # obs row | reward | done | info
+        self._h_slab = torch.zeros((nb + 16,), dtype=torch.uint8, pin_memory=True)
+        self._h_obs = self._h_slab[:nb].view(torch.float32).view(1, v.obs_dim)
+        v.bind_outputs(self._d_slab[nb:nb + 4].view(torch.float32), self._d_slab[nb + 4:nb + 5], self._d_slab[nb + 5:nb + 6],
+                       obs=self._d_slab[:nb].view(torch.float32).view(1, v.obs_dim))
+        self._nb = nb
+        # the action goes up through a page-locked word as well (a pageable torch.as_tensor(...).to(device) is a
+        # synchronous copy of its own)
+        am = v.cfg.action_mode
+        act_dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        act_shape = (1, 2) if am == capi.ACT_PAIR else (1,)
+        self._h_act = torch.zeros(act_shape, dtype=act_dt, pin_memory=True)
+        self._d_act = torch.zeros(act_shape, dtype=act_dt, device=v.device)
+        self._h_side = torch.zeros((2,), dtype=torch.int32, pin_memory=True)   # no_conflict | nearest distance bits
         self._no_conflict = 0
 
     def _fetch(self, obs):
         """Bring the observation row and the scalar slab to the host with one synchronisation."""
         v = self._vec
-        capi.check(v._lib.uam_counters(v._h, self._d_nc.data_ptr(), v._stream()))
-        self._h_obs.copy_(obs, non_blocking=True)
-        self._h_slab.copy_(self._d_slab, non_blocking=True)
+        capi.check(v._lib.uam_counters(v._h, self._h_side.data_ptr(), v._stream()))     # straight into host memory
+        self._h_slab.copy_(self._d_slab, non_blocking=True)          # observation row and scalars in one copy
         v._torch.cuda.current_stream(v.device).synchronize()
-        h = self._h_slab.numpy()
-        self._no_conflict = int(h[8:12].view(np.int32)[0])
+        h = self._h_slab.numpy()[self._nb:]
+        self._no_conflict = int(self._h_side[0])
         return float(h[0:4].view(np.float32)[0]), bool(h[4]), int(h[5])
 
     def seed(self, seed=None):
@@ -440,7 +455,9 @@ class SingleAircraftEnv:
         return [int(action)]
 
     def _step_host(self, action):
-        obs, _, _, _ = self._vec.step(self._encode_action(action))
+        self._h_act.numpy()[...] = np.asarray(self._encode_action(action)).reshape(self._h_act.shape)
+        self._d_act.copy_(self._h_act, non_blocking=True)
+        obs, _, _, _ = self._vec.step(self._d_act)
         rew, done, code = self._fetch(obs)
         return self._obs_np(self._h_obs), rew, done, code
 
@@ -551,10 +568,10 @@ class SingleAircraftDiscrete3HEREnv(SingleAircraftDiscrete9HEREnv):
 
     def _fetch(self, obs):
         v = self._vec
-        if v.cfg.shaped_reward:      # the nearest-intruder distance rides in the same slab (bytes 12..15)
-            capi.check(v._lib.uam_nearest(v._h, self._d_slab[12:16].view(v._torch.float32).data_ptr(), v._stream()))
+        if v.cfg.shaped_reward:      # the nearest-intruder distance lands next to no_conflict in host memory
+            capi.check(v._lib.uam_nearest(v._h, self._h_side.data_ptr() + 4, v._stream()))
         out = super()._fetch(obs)
-        self._nearest = float(self._h_slab.numpy()[12:16].view(np.float32)[0])
+        self._nearest = float(self._h_side.numpy()[1:2].view(np.float32)[0])
         return out
 
     def step(self, action):

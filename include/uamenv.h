@@ -223,7 +223,8 @@ int uam_episode_stats(uam_env* env, double* ret_out_dev, int32_t* len_out_dev, v
  * Needs uam_config.shaped_reward = 1 (the only mode that tracks it). */
 int uam_nearest(uam_env* env, float* nearest_out_dev, void* stream);
 
-/* Copy env.no_conflict (int32[B]) to a device buffer. */
+/* Copy env.no_conflict (int32[B]) to a device buffer (or to page-locked host memory: the copy is stream-ordered
+ * either way; the same holds for uam_nearest). */
 int uam_counters(uam_env* env, int32_t* no_conflict_out_dev, void* stream);
 
 /* Synchronous host<->device state exchange (see uam_state_view). */
