@@ -9,8 +9,8 @@ state, action tape) are resident in HBM before the timed region; observations, r
 stay on the device.  With N>1 every rank owns 65536 envs (weak scaling, env_id_offset = rank*B so
 the union is one consistent batch) and the per-chunk reward/done slabs are all-gathered with RCCL.
 
-One step is two dependent launches (uam_own_kernel: fp64 ownship kinematics, one thread per env;
-uam_sweep_kernel: the intruder sweep / reduction / respawn / obs pack, one lane group per env).
+One step is one launch of uam_sweep_kernel: the fp64 ownship phase (one thread per env, handed over through
+LDS) and the intruder sweep / reduction / respawn / obs pack (one lane group per env).
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : for the dominant kernel (uam_sweep_kernel): algorithmic HBM bytes per launch
@@ -183,12 +183,10 @@ def main():
         total_env_steps = float(B) * world * args.steps
         value = total_env_steps / elapsed
         step_bytes = env.step_bytes                      # (40 N + 150) B per env-step, SURVEY §8d
-        fused = own_ms == 0.0                            # float32/Philox: ownship phase runs inside the sweep launch
-        own_bytes = 0 if fused else 88 * B               # ownship/goal/action/counter share of the 150 B
-        sweep_bytes = step_bytes - own_bytes             # what the dominant kernel must move per launch
-        # fused: the step IS the sweep launch, so the hipEvents that bracket the timed region (divided by the
-        # launches) give its average duration without the perturbation of per-launch event records
-        dom_ms = kernel_ms if fused else sweep_ms
+        sweep_bytes = step_bytes                         # the step is one launch: it moves all of the step's bytes
+        # the hipEvents that bracket the timed region (divided by the launches) give the kernel's average duration
+        # without the perturbation of per-launch event records (`bracketed_launch_ms` is that perturbed figure)
+        dom_ms = kernel_ms
         achieved = sweep_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
@@ -210,7 +208,7 @@ def main():
             "pair_steps_per_sec": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "uam_sweep_kernel (ownship phase fused)" if fused else "uam_sweep_kernel",
+                         "kernel": "uam_sweep_kernel (ownship phase + intruder sweep, one launch per step)",
                          "bytes_per_launch": sweep_bytes,
                          "avg_launch_ms": dom_ms, "bracketed_launch_ms": sweep_ms, "sampled_launches": nsamp,
                          "own_kernel_avg_ms": own_ms,

@@ -5,14 +5,13 @@
  * observe / policy kernels and the two RNGs (Philox4x32-10, NumPy-legacy
  * MT19937 with lazy per-word twist).
  *
- * Execution shape (CDNA4, wave64) — one env.step() is ONE launch in every Philox configuration (the
- * ownship phase runs inside uam_sweep_kernel, one thread per env, and is handed over through LDS) and
- * two dependent launches in the NumPy-compatible MT19937 mode:
- *   uam_own_kernel   one THREAD per env: the fp64 ownship kinematics, goal distance, env-level reward
- *                    tail and the ownship/goal part of the observation (coalesced over envs); result
- *                    handed over as a 48-byte record per env (own_compute(): the same code is the
- *                    fused phase).  fp64 trig needs ~96 VGPRs; the threads that run it fetch their
- *                    quad afterwards, so the sweep still runs at 8 waves/SIMD.
+ * Execution shape (CDNA4, wave64) — one env.step() is ONE launch, uam_sweep_kernel:
+ *   ownship phase    the first E threads of the block run own_compute() for the block's E envs, one THREAD
+ *                    per env (coalesced over envs): the fp64 ownship kinematics, goal distance, env-level
+ *                    reward tail and the ownship/goal part of the observation, handed to the lane groups
+ *                    as a 48-byte record per env through LDS; one block barrier later everyone sweeps.
+ *                    fp64 trig needs ~96 VGPRs; the threads that run it fetch their quad afterwards, so
+ *                    the sweep still runs at 8 waves/SIMD.
  *   uam_sweep_kernel one env is owned by a sub-wave group of L = next_pow2(ceil(N/4)) lanes; a lane
  *                    owns a "quad" of 4 consecutive intruders, so every intruder field moves with
  *                    16-byte accesses and a wave touches 1 KiB of contiguous SoA per instruction.
@@ -74,7 +73,6 @@ struct UamDev {
     int32_t* no_conflict;
     uint32_t* reset_count; /* [B] episodes started so far: Philox counter of the reset draws */
     float*   nearest;   /* [B] distance to the nearest swept intruder of the last step (shaped_reward only) */
-    float4*  share;     /* [B*3] OwnShare records handed from uam_own_kernel to uam_sweep_kernel */
     double*  ep_ret;    /* [B] running episode return / length and those of the last finished episode */
     int32_t* ep_len;
     double*  ep_last_ret;
@@ -130,7 +128,7 @@ struct UamParams {
     void* actions_out;
 };
 
-/* what uam_own_kernel hands to the env's lane group (48 B per env, three float4) */
+/* what the ownship phase hands to the env's lane group through LDS (48 B per env, three float4) */
 struct OwnShare {
     float own_x, own_y;
     float rew_tail;      /* reward if neither NMAC nor conflict: goal reward or dense/sparse step reward */
@@ -916,22 +914,14 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     sh[2] = make_float4(t[4], t[5], t[6], t[7]);
 }
 
-template <int RNG>
-__global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const UamCold c)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.B) return;
-    own_compute<RNG>(p, c, e, p.s.share + (size_t)e * 3);
-}
-
-/* ------------------------------------------------------------------ launch 2: the intruder sweep
- * _terminal_reward :146-185 (RandIntruder :181-204), reset_intruder, auto-reset, _get_ob.
- * LDS (aligned obs only): E*D floats of per-wave obs staging.  No block-level barrier. */
-/* FUSED: the ownship phase runs inside this launch — the first E threads of the block compute the
- * block's E envs (one thread per env) while the other waves already have their quad loads in flight,
- * hand the 48-byte records over through LDS, and one block barrier later everyone sweeps.  Saves the
- * separate launch (5.5 us of pure latency at B=65536).  Used by every Philox configuration; the threads
- * that run the ownship phase fetch their quad after it, so the phase never adds register pressure. */
+/* ------------------------------------------------------------------ the step kernel
+ * Ownship.step + _terminal_reward :146-185 (RandIntruder :181-204), reset_intruder, auto-reset, _get_ob.
+ * LDS: E*48 B of ownship records, then (aligned obs only) E*D floats of per-wave obs staging.
+ * The ownship phase runs inside this launch — the first E threads of the block compute the block's E envs
+ * (one thread per env) while the other waves already have their quad loads in flight, hand the 48-byte
+ * records over through LDS, and one block barrier later everyone sweeps (a separate ownship launch cost
+ * 5.5 us of pure latency at B=65536).  The threads that run the ownship phase fetch their quad after it, so
+ * the phase never adds register pressure. */
 /* MODE bits: 1 RandIntruder dynamics, 2 reward shaped by the nearest swept intruder, 4 k-nearest observation */
 #define UAM_MODE_RI 1
 #define UAM_MODE_SHAPED 2
@@ -939,7 +929,7 @@ __global__ void __launch_bounds__(64) uam_own_kernel(const UamParams p, const Ua
 /* one step of the sweep for this block.  k = step within the launch (0 for uam_sweep_kernel; the loop index of
  * uam_sweep_many_kernel): the Philox step counter, the action / noise / reward / done / info rows advance with it;
  * with_obs = this step emits the observation. */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED, bool KC = false>
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false>
 __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, const bool with_obs)
 {
     typedef typename PosT<POS64>::type P;
@@ -951,14 +941,13 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     const int env = blockIdx.x * p.E + g;
     const int wave_first_g = (tid & ~63) >> p.lshift;
     const int env_first = blockIdx.x * p.E + wave_first_g;
-    if (!FUSED && env_first >= p.B) return;          /* whole wave past the batch end */
     const bool env_ok = env < p.B;
     const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
     Quad<POS64, SH> q;
-    float4* lds_share = (float4*)lds_raw;            /* FUSED: [E][3] float4, then the obs staging */
-    if constexpr (FUSED) {
+    float4* lds_share = (float4*)lds_raw;            /* [E][3] float4, then the obs staging */
+    {
         /* threads that run the ownship phase fetch their quad AFTER it, so the fp64 phase and the
          * quad never share the register file (keeps the kernel at 64 VGPRs = 8 waves/SIMD); every
          * other thread has its loads in flight while it waits at the barrier */
@@ -972,12 +961,9 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();
-        if (env_first >= p.B) return;
-    } else {
-        quad_load<POS64, SH>(p, base, quad_ok, q);
+        if (env_first >= p.B) return;                /* whole wave past the batch end */
     }
-    const float4* shp = FUSED ? (const float4*)(lds_share + 3 * (env_ok ? g : wave_first_g))
-                              : (const float4*)(p.s.share + (size_t)(env_ok ? env : env_first) * 3);
+    const float4* shp = (const float4*)(lds_share + 3 * (env_ok ? g : wave_first_g));
     const float4 s0 = shp[0];              /* same address for the whole lane group: one broadcast load */
     const float ox = s0.x, oy = s0.y;
 
@@ -1220,7 +1206,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (with_obs && p.obs && !(UAM_ABLATE & 2)) {
-        float* stage = (float*)(lds_raw + (FUSED ? (size_t)p.E * 48 : 0)) + (size_t)wave_first_g * p.D;
+        float* stage = (float*)(lds_raw + (size_t)p.E * 48) + (size_t)wave_first_g * p.D;
         if constexpr (KNN) {
             float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
             knn_row<POS64, SH>(p, row, gl, L, env_ok, quad_ok, q, kx, ky, tail);
@@ -1231,14 +1217,14 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     }
 }
 
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool FUSED>
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     /* exact-promotion Philox instances: the fp64 spawn sits inside the respawn loop, and the SGPR-pinned sincos
      * flavour keeps its literals out of the VGPRs held across that loop (131 -> 91 VGPRs, -6 % step time).  The
      * RandIntruder and MT19937 instances measure slower with it (+3...16 %) and keep the plain flavour. */
-    sweep_step<POS64, RNG, MODE, SH, ROS, FUSED, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, true);
+    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, true);
 }
 
 /* K consecutive steps in ONE launch (uam_step_many, Philox): envs never interact and a block only ever touches
@@ -1253,7 +1239,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_many_kernel(const UamParams p)
     const int K = p.many_K;
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, k == K - 1);
+        sweep_step<POS64, RNG, MODE, SH, ROS, true>(p, lds_raw, k, k == K - 1);
         __syncthreads();
     }
 }

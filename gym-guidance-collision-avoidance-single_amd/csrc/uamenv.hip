@@ -47,9 +47,8 @@ struct uam_env {
     std::vector<hipEvent_t> kev;  /* 3 events per sampled step (before own, between, after sweep) */
     bool ktiming;
     int ksamples;
-    bool fused;                 /* lean configuration: ownship phase fused into the sweep launch */
     UamCold* cold;              /* device copy of the cold configuration */
-    UamCold hcold;              /* host copy, passed by value to the ownship kernel */
+    UamCold hcold;              /* host copy of the cold configuration */
     UamDev s;
     std::vector<void*> allocs;
     hipEvent_t ev0, ev1;
@@ -289,8 +288,6 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
     /* Philox configurations run the ownship phase inside the sweep launch (one launch per step); the
      * MT19937 stream and the random-ownship-start variant keep the separate ownship kernel */
-    e->fused = cfg->rng_mode == UAM_RNG_PHILOX;
-    if (const char* fz = getenv("UAMENV_FUSED")) e->fused = e->fused && atoi(fz) != 0;   /* development override */
 
     const size_t BI = (size_t)B * e->Np;
     memset(&e->s, 0, sizeof(e->s));
@@ -323,7 +320,6 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (!rc) rc = dev_alloc(e, &e->s.goal_y, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.no_conflict, (size_t)B);
     if (!rc) rc = dev_alloc(e, &e->s.reset_count, (size_t)B);
-    if (!rc) rc = dev_alloc(e, &e->s.share, (size_t)B * 3);
     if (cfg->shaped_reward && !rc) rc = dev_alloc(e, &e->s.nearest, (size_t)B);
     if (cfg->track_episodes) {
         if (!rc) rc = dev_alloc(e, &e->s.ep_ret, (size_t)B);
@@ -414,20 +410,11 @@ template <bool POS64, int RNG, int RI, bool SH>
 static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t st)
 {
     dim3 grid(grid_of(e)), block(e->T);
-    const size_t lds = lds_stage(e, p);
-    if constexpr (RNG == UAM_RNG_PHILOX) {
-        if (e->fused) {   /* ownship phase inside the sweep launch */
-            if (e->cfg.random_own_start)
-                hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, true>), grid, block, lds + (size_t)e->E * 48, st, p);
-            else
-                hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, true>), grid, block, lds + (size_t)e->E * 48, st, p);
-            return;
-        }
-    }
+    const size_t lds = lds_stage(e, p) + (size_t)e->E * 48;      /* obs staging + the ownship records */
     if (e->cfg.random_own_start)
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true, false>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true>), grid, block, lds, st, p);
     else
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false, false>), grid, block, lds, st, p);
+        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false>), grid, block, lds, st, p);
 }
 
 template <bool POS64, int RNG>
@@ -473,11 +460,12 @@ static bool many_supported(const uam_env* e)
     /* the looped kernel holds 115-166 VGPRs (3 waves/SIMD at worst = 3 of these 4-wave blocks per CU): it only pays
      * while the whole grid is resident in one round — which is exactly the launch-bound small-batch regime */
     const int resident_blocks = 256 * 3 * 256 / e->T;
-    return e->fused && e->cfg.precision == UAM_POS_F32 && !(e->cfg.shaped_reward && e->hold_sh) && !e->ktiming &&
+    return e->cfg.rng_mode == UAM_RNG_PHILOX && e->cfg.precision == UAM_POS_F32 &&
+           !(e->cfg.shaped_reward && e->hold_sh) && !e->ktiming &&
            grid_of(e) <= resident_blocks;
 }
 
-/* one env.step(): ownship kernel (thread per env) then the intruder sweep (lane group per env) */
+/* one env.step() = one launch: ownship phase (thread per env) and intruder sweep (lane group per env) */
 static const int KTIMING_MAX = 256;
 
 static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
@@ -485,13 +473,7 @@ static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
     const bool sample = e->ktiming && e->ksamples < KTIMING_MAX;
     hipEvent_t* ev = sample ? &e->kev[(size_t)3 * e->ksamples] : nullptr;
-    dim3 ogrid((e->cfg.num_envs + 63) / 64), oblock(64);
-    if (sample) (void)hipEventRecord(ev[0], st);
-    if (!e->fused) {
-        if (mt) hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_MT19937>), ogrid, oblock, 0, st, p, e->hcold);
-        else hipLaunchKernelGGL((uam_own_kernel<UAM_RNG_PHILOX>), ogrid, oblock, 0, st, p, e->hcold);
-    }
-    if (sample) (void)hipEventRecord(ev[1], st);
+    if (sample) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
     if (x && mt) launch_sweep_t<true, UAM_RNG_MT19937>(e, p, st);
     else if (x) launch_sweep_t<true, UAM_RNG_PHILOX>(e, p, st);
     else if (mt) launch_sweep_t<false, UAM_RNG_MT19937>(e, p, st);
@@ -793,15 +775,14 @@ extern "C" int uam_kernel_timing_read(uam_env* e, void* stream, float* own_ms_ou
     if (!e || !own_ms_out || !sweep_ms_out || !samples_out) return fail(UAM_EINVAL, "NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    double own = 0, sweep = 0;
+    double sweep = 0;
     for (int i = 0; i < e->ksamples; i++) {
-        float a = 0, b = 0;
-        HIP_TRY(hipEventElapsedTime(&a, e->kev[(size_t)3 * i], e->kev[(size_t)3 * i + 1]));
+        float b = 0;
         HIP_TRY(hipEventElapsedTime(&b, e->kev[(size_t)3 * i + 1], e->kev[(size_t)3 * i + 2]));
-        own += a; sweep += b;
+        sweep += b;
     }
     *samples_out = e->ksamples;
-    *own_ms_out = (e->ksamples && !e->fused) ? (float)(own / e->ksamples) : 0.f;   /* fused: no separate ownship launch */
+    *own_ms_out = 0.f;   /* the ownship phase runs inside the sweep launch: there is no separate ownship launch */
     *sweep_ms_out = e->ksamples ? (float)(sweep / e->ksamples) : 0.f;
     e->ksamples = 0;
     return UAM_OK;

@@ -186,8 +186,7 @@ int uam_seed(uam_env* env, const uint64_t* seeds_host);
  * obs_out: float32[B, D] device or NULL; rows of un-masked envs receive their current observation. */
 int uam_reset(uam_env* env, const uint8_t* mask_dev, float* obs_out, void* stream);
 
-/* One env.step() for every env of the batch: one launch in the float32/Philox configuration (ownship
- * phase fused into the intruder sweep), two dependent launches otherwise.
+/* One env.step() for every env of the batch: one kernel launch (ownship phase and intruder sweep).
  *   actions   : device, per uam_config.action_mode
  *   obs_out   : float32[B, D] device or NULL
  *   reward_out: float32[B]   device
@@ -261,11 +260,11 @@ int64_t uam_step_bytes(const uam_env* env);
 int uam_timing_begin(uam_env* env, void* stream);
 int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
 
-/* Per-kernel device times.  While enabled, every uam_step brackets its two launches with hipEvents
- * (up to 256 steps are sampled; this serialises the launches slightly, so keep it out of throughput
- * runs).  uam_kernel_timing_read synchronises `stream` and returns the mean duration in milliseconds of
- * the ownship kernel and of the intruder-sweep kernel over the sampled steps (the ownship figure is 0
- * in the float32/Philox configuration, where that phase runs inside the sweep launch). */
+/* Per-kernel device times.  While enabled, every uam_step brackets its launch with hipEvents (up to 256
+ * steps are sampled; this serialises the launches slightly, so keep it out of throughput runs).
+ * uam_kernel_timing_read synchronises `stream` and returns the mean duration in milliseconds of the step
+ * kernel over the sampled steps in sweep_ms_out; own_ms_out is always 0 (the ownship phase runs inside the
+ * same launch; the argument is kept for ABI stability). */
 int uam_kernel_timing(uam_env* env, int32_t enable);
 int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out);
 
