@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets 2 ranks share one GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "gather", "none"],
+                    help="N>1: how the per-chunk reward/done slab is exchanged (gather = to rank 0 only; none = exploration)")
     ap.add_argument("--variant", default="discrete9", help="exploration only: env variant (default = the BASELINE workload)")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
@@ -124,7 +126,8 @@ def main():
 
     slabs = [make_slab(), make_slab()]
     pending = [None, None]
-    gathered = [torch.empty((world * KB * 5,), dtype=torch.uint8, device=dev) for _ in range(2)] if world > 1 else None
+    need_all = world > 1 and (args.exchange == "all_gather" or (args.exchange == "gather" and rank == 0))
+    gathered = [torch.empty((world * KB * 5,), dtype=torch.uint8, device=dev) for _ in range(2)] if need_all else None
     acts = env.policy_actions("random")
 
     def run(nsteps, offset=0):
@@ -141,9 +144,13 @@ def main():
                 pending[c] = None
             raw, rew_slab, done_slab = slabs[c]
             env.step_into(a, rew_slab[j], done_slab[j])
-            if world > 1 and j == GATHER_EVERY - 1:
-                # the one exchange of the path: the chunk's reward/done slab, all-gathered over xGMI (RCCL)
-                pending[c] = dist.all_gather_into_tensor(gathered[c], raw, async_op=True)
+            if world > 1 and j == GATHER_EVERY - 1 and args.exchange != "none":
+                # the one exchange of the path: the chunk's reward/done slab over xGMI (RCCL)
+                if args.exchange == "all_gather":
+                    pending[c] = dist.all_gather_into_tensor(gathered[c], raw, async_op=True)
+                else:
+                    pending[c] = dist.gather(raw, gather_list=list(gathered[c].view(world, -1).unbind(0)) if rank == 0 else None,
+                                             dst=0, async_op=True)
 
     def drain():
         for c in (0, 1):
@@ -203,8 +210,9 @@ def main():
                        else "%s variant, batch=%d x %d intruders per GPU" % (args.variant, B, N),
                        "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": args.rng,
                        "variant": args.variant, "positions": "float32" if args.precision == "f32" else "float64 (exact promotion)", "obs": "float32[B,%d] written every step" % env.obs_dim,
-                       "exchange": "none" if world == 1 else "one async all_gather of the [%d, B] reward+done slab per chunk, "
-                                   "double-buffered (overlaps the next chunk)" % GATHER_EVERY},
+                       "exchange": "none" if world == 1 or args.exchange == "none" else
+                                   "one async %s of the [%d, B] reward+done slab per chunk, double-buffered "
+                                   "(overlaps the next chunk)" % (args.exchange, GATHER_EVERY)},
             "pair_steps_per_sec": value * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
