@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: batched SingleAircraftEnv.step() on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE fused uam_step launch over the whole per-GPU batch (BASELINE.json configs[2]:
-discrete-9, 65536 envs x 32 intruders, the configuration the metric is quoted on).  Inputs (env
-state, action tape) are resident in HBM before the timed region; observations, rewards and dones
-stay on the device.  With N>1 every rank owns 65536 envs (weak scaling, env_id_offset = rank*B so
-the union is one consistent batch) and the per-chunk reward/done slabs are all-gathered with RCCL.
+A "step" is ONE pass of the hot path (one fused uam_sweep_kernel launch) over the rank's whole batch.  Inputs (env
+state, action tape) are resident in HBM before the timed region; observations (written every step), rewards and
+dones stay on the device.  Steps are issued in rollout chunks through the C-ABI (`uam_rollout`: the K launches of a
+chunk are queued by one call, no Python between them), and with N>1 the chunk's reward/done slab is exchanged with
+ONE asynchronous RCCL collective that overlaps the next chunk (uamenv.sharded.RolloutExchange).
 
-One step is one launch of uam_sweep_kernel: the fp64 ownship phase (one thread per env, handed over through
-LDS) and the intruder sweep / reduction / respawn / obs pack (one lane group per env).
+N>1 without WORLD_SIZE in the environment: this process never touches the GPU; it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, passes its output through and exits
+with its status.  Under torch.distributed.run (how the driver starts N>1) every rank runs main() directly.
 
-Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : for the dominant kernel (uam_sweep_kernel): algorithmic HBM bytes per launch
-                 (SURVEY §8d accounting) / its average launch duration, measured live
-                 with hipEvents bracketing that kernel on the launch stream in a separate 256-step pass
-                 after the timed region, against the 8 TB/s HBM3E peak.  `traffic` is the PMC figure
-                 (FETCH_SIZE x2 + WRITE_SIZE per launch) committed under profiles/, when present,
-  cpu_baseline : the CPU oracle (a port of the reference's step()) timed on this host's cores on a
-                 bounded sample of the same workload (rank 0, N=1 only).
+Two workloads are measured in every invocation, the first is `value`:
+  weak   (default)   BASELINE.json configs[2]: SingleAircraftEnv discrete-9, 65536 envs x 32 intruders PER GPU
+                     (the configuration the metric is quoted on; at N=1 it is exactly the roofline run).
+  strong (field)     BASELINE.json configs[3]: SingleAircraft2Env continuous, ONE batch of 65536 envs x 32
+                     intruders partitioned over the ranks by shard_bounds (8192 per GPU at N=8); small shards run
+                     their chunk as one looped launch (uam_sweep_many_kernel).
+`--scaling strong` swaps them (`--variant` then picks the env of the primary workload).
+
+Prints ONE JSON line (rank 0): the contract fields, plus
+  reps_ms      : wall time of every repetition of the K-step region; `ms_per_step`/`value` come from the median
+  roofline     : dominant kernel of the primary workload: algorithmic HBM bytes per launch (SURVEY §8d accounting,
+                 DESIGN.md §5) / its average duration from hipEvents bracketing the timed region on the launch stream,
+                 against the 8 TB/s HBM3E peak; `hbm_resident` repeats it at 1 M envs (1.5 GB per step, beyond the
+                 256 MiB Infinity Cache) next to a plain device copy of the same bytes
+  cpu_baseline : the CPU oracle (a C port of the reference's step()) on this host's cores, bounded sample (N=1 only)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,207 +42,385 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
-B_PER_GPU = 65536
+GLOBAL_BATCH = 65536    # BASELINE.json configs[2]/[3]
 N_INTRUDERS = 32
 TAPE_LEN = 64
-GATHER_EVERY = 32
+PMC_PROFILE = os.path.join("profiles", "r02_pmc_summary.json")
+# measured in the build container by importing the reference; cannot be re-measured on the GPU box
+REF_PYTHON = {"env_steps_per_sec_per_core": 3.4e3, "where": "reference NumPy step() at N=32, build container "
+              "(8 vCPU Xeon 2.1 GHz), one process per core; BASELINE.md §2 — measured elsewhere, not on this box"}
 
 
-def cpu_baseline(nthreads, seconds_target=12.0):
-    """Oracle (kind 'port') on a bounded sample: same env config, random actions, all host threads."""
-    import numpy as np
-    from oracle import oracle
-    oracle.build()
-    B, N = 8192, N_INTRUDERS
-    cfg = oracle.default_config(B, N, rng_mode=oracle.RNG_PHILOX, precision=oracle.POS_F32, auto_reset=1, seed=0)
-    env = oracle.OracleBatch(cfg, oracle.MATH_PORTABLE, threads=nthreads)
-    env.reset(want_obs=False)
-    rs = np.random.RandomState(1)
-    acts = rs.randint(0, 9, size=(TAPE_LEN, B)).astype(np.int32)
-    for k in range(3):
-        env.step(acts[k], want_obs=True)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        for k in range(10):
-            env.step(acts[(steps + k) % TAPE_LEN], want_obs=True)
-        steps += 10
-        el = time.perf_counter() - t0
-        if el >= seconds_target or steps >= 2000:
-            break
-    env.close()
-    return {"value": B * steps / el, "unit": "env-steps/s", "cores": nthreads, "kind": "port",
-            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, %d steps, random actions, "
-                      "float64 obs written" % (B, N, steps)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="envs per GPU")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region (median is reported)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="which workload is `value`")
+    ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="weak: envs per GPU; strong: envs in total")
     ap.add_argument("--intruders", type=int, default=N_INTRUDERS)
-    ap.add_argument("--policy", default="random", choices=["random", "goal"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets 2 ranks share one GPU box")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--variant", default=None, help="env of the primary workload (default: discrete9 for weak, "
+                    "continuous for strong = BASELINE configs[2] / [3])")
+    ap.add_argument("--policy", default="random", choices=["random", "goal"],
+                    help="random: action tape in HBM; goal: goal-seeking policy kernel before every step (closed loop)")
+    ap.add_argument("--chunk", type=int, default=0, help="steps per rollout chunk / exchange (0 = 32 at 65536 envs "
+                    "per GPU, growing to 256 for smaller shards)")
+    ap.add_argument("--obs-slots", type=int, default=1, help="observation slots of a chunk: 1 = one [B,D] buffer "
+                    "overwritten every step, 2 = double buffer, 0 = the full [K,B,D] rollout slab")
     ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "gather", "none"],
-                    help="N>1: how the per-chunk reward/done slab is exchanged (gather = to rank 0 only; none = exploration)")
-    ap.add_argument("--variant", default="discrete9", help="exploration only: env variant (default = the BASELINE workload)")
+                    help="N>1: the per-chunk collective of the reward/done slab (gather = to rank 0 only)")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second workload and the 1 M-env pass")
+    ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets 2 ranks share one GPU box")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    return ap.parse_args(argv)
 
-    import torch
+
+def self_launch(args):
+    """N>1 and no rendezvous in the environment: start the ranks as children.  Runs BEFORE anything imports torch
+    or touches the GPU in this process (a process that has initialised the GPU must never exec/fork ranks)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(B, N, nthreads):
+    """Oracle (kind 'port') on a bounded sample of the same workload: all host threads, then one thread."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    cfg = oracle.default_config(B, N, rng_mode=oracle.RNG_PHILOX, precision=oracle.POS_F32, auto_reset=1, seed=0)
+    rs = np.random.RandomState(1)
+    acts = rs.randint(0, 9, size=(8, B)).astype(np.int32)
+
+    def rate(threads, seconds):
+        env = oracle.OracleBatch(cfg, oracle.MATH_PORTABLE, threads=threads)
+        env.reset(want_obs=False)
+        env.step(acts[0], want_obs=True)
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            env.step(acts[steps % 8], want_obs=True)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or steps >= 4000:
+                break
+        env.close()
+        return B * steps / el, steps
+
+    v_all, s_all = rate(nthreads, 8.0)
+    v_one, s_one = rate(1, 6.0)
+    return {"value": v_all, "unit": "env-steps/s", "cores": nthreads, "kind": "port",
+            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, %d steps on %d threads "
+                      "(+ %d steps on 1 thread), random actions, float64 obs written" % (B, N, s_all, nthreads, s_one),
+            "single_thread": v_one, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+            "reference_python": REF_PYTHON}
+
+
+class Ctx:
+    pass
+
+
+def median(xs):
+    s = sorted(xs)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
+def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed):
+    """One workload on this rank's shard: spin-up, `warmup` untimed steps, then `reps` repetitions of exactly `steps`
+    steps, each bracketed by barrier + synchronize; max over ranks per repetition."""
+    torch, dist = ctx.torch, ctx.dist
     import uamenv
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
-
-    B, N = args.batch, args.intruders
-    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=args.variant, rng=args.rng, precision=args.precision, seed=0,
-                                          auto_reset=True, device=local_rank, env_id_offset=rank * B)
+    from uamenv.sharded import RolloutExchange, shard_bounds
+    from uamenv import _capi as capi
+    N = args.intruders
+    if scaling == "weak":
+        counts = [args.batch] * ctx.world
+        first = ctx.rank * args.batch
+    else:
+        spans = [shard_bounds(args.batch, ctx.world, r) for r in range(ctx.world)]
+        counts = [c for _, c in spans]
+        first = spans[ctx.rank][0]
+    B = counts[ctx.rank]
+    K = args.chunk if args.chunk > 0 else max(32, min(256, 32 * GLOBAL_BATCH // max(B, 1)))
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, rng=args.rng, precision=args.precision, seed=0,
+                                          auto_reset=True, device=ctx.local_rank, env_id_offset=first)
     dev = env.device
     env.reset()
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1 + rank)
-    if env.cfg.action_mode == 0:
-        tape = torch.randint(0, 9, (TAPE_LEN, B), dtype=torch.int32, device=dev, generator=gen)
-    elif env.cfg.action_mode == 1:
-        tape = torch.randint(0, 3, (TAPE_LEN, B, 2), dtype=torch.int32, device=dev, generator=gen)
+    gen.manual_seed(1 + ctx.rank)
+    am = env.cfg.action_mode
+    TL = max(TAPE_LEN, K)
+    if am == capi.ACT_DISCRETE9:
+        tape = torch.randint(0, 9, (TL, B), dtype=torch.int32, device=dev, generator=gen)
+    elif am == capi.ACT_PAIR:
+        tape = torch.randint(0, 3, (TL, B, 2), dtype=torch.int32, device=dev, generator=gen)
+    elif am == capi.ACT_DISCRETE3:
+        tape = torch.randint(0, 3, (TL, B), dtype=torch.int32, device=dev, generator=gen)
     else:
-        tape = torch.rand((TAPE_LEN, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
-    # Chunk slabs: rewards (float32) and dones (uint8) of GATHER_EVERY steps live in ONE byte buffer so that a
-    # single collective moves both; two slabs alternate so the gather of chunk c overlaps the steps of chunk c+1.
-    KB = GATHER_EVERY * B
+        tape = torch.rand((TL, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
+    tape = torch.cat([tape, tape[:K]]).contiguous()       # any chunk of <= K rows is one contiguous slice
+    R = K if args.obs_slots == 0 else args.obs_slots
+    obs_slots = torch.empty((R, B, env.obs_dim), dtype=torch.float32, device=dev)
+    info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    ex = RolloutExchange(dist, K, counts, ctx.rank, dev, mode=args.exchange)
+    looped = int(env.steps_per_launch(K)) > 1 and args.policy == "random"
+    acts = env.policy_actions("random") if args.policy == "goal" else None
+    state = {"chunk": 0, "launches": 0}
 
-    def make_slab():
-        raw = torch.empty((KB * 5,), dtype=torch.uint8, device=dev)
-        return raw, raw[:KB * 4].view(torch.float32).view(GATHER_EVERY, B), raw[KB * 4:].view(GATHER_EVERY, B)
-
-    slabs = [make_slab(), make_slab()]
-    pending = [None, None]
-    need_all = world > 1 and (args.exchange == "all_gather" or (args.exchange == "gather" and rank == 0))
-    gathered = [torch.empty((world * KB * 5,), dtype=torch.uint8, device=dev) for _ in range(2)] if need_all else None
-    acts = env.policy_actions("random")
-
-    def run(nsteps, offset=0):
-        for k in range(nsteps):
-            i = offset + k
-            if args.policy == "goal":
-                a = env.policy_actions("goal", out=acts)
+    def run(nsteps, start):
+        i = 0
+        while i < nsteps:
+            k = min(K, nsteps - i)
+            c = state["chunk"] & 1
+            ex.begin(c)                 # the stream (not the host) waits until this slab's last collective has read it
+            rew, done = ex.slab(c)
+            if args.policy == "goal":   # closed loop: policy kernel, then one step, per step
+                for j in range(k):
+                    env.policy_actions("goal", out=acts)
+                    env.step_into(acts, rew[j], done[j])
             else:
-                a = tape[i % TAPE_LEN]
-            # rewards/dones land directly in row j of the chunk slab: identical per-step work at every N
-            c, j = (i // GATHER_EVERY) & 1, i % GATHER_EVERY
-            if j == 0 and pending[c] is not None:
-                pending[c].wait()            # the stream (not the host) waits until this slab's last gather is done
-                pending[c] = None
-            raw, rew_slab, done_slab = slabs[c]
-            env.step_into(a, rew_slab[j], done_slab[j])
-            if world > 1 and j == GATHER_EVERY - 1 and args.exchange != "none":
-                # the one exchange of the path: the chunk's reward/done slab over xGMI (RCCL)
-                if args.exchange == "all_gather":
-                    pending[c] = dist.all_gather_into_tensor(gathered[c], raw, async_op=True)
-                else:
-                    pending[c] = dist.gather(raw, gather_list=list(gathered[c].view(world, -1).unbind(0)) if rank == 0 else None,
-                                             dst=0, async_op=True)
-
-    def drain():
-        for c in (0, 1):
-            if pending[c] is not None:
-                pending[c].wait()
-                pending[c] = None
+                t0 = (start + i) % TL
+                env.rollout_into(tape[t0:t0 + k], rew[:k], done[:k], info[:k], obs_slots)
+            state["launches"] += 1 if (looped and k > 1) else k
+            ex.exchange(c)              # the one exchange of the path: the chunk's reward/done slab over xGMI
+            state["chunk"] += 1
+            i += k
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if ctx.world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    run(args.warmup)
-    drain()
-    fence()
-    env.timing_begin()
-    t0 = time.perf_counter()
-    run(args.steps, offset=args.warmup)
-    drain()
-    kernel_ms = env.timing_end()      # hipEvents on the launch stream, averaged over the uam_step launches
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # untimed spin-up (clock ramp, first-launch costs), not part of the driver-counted warmup.  Time-based, so it
+    # must not contain a collective (ranks would disagree on the count): plain rollouts into slab 0, no exchange
+    if args.policy == "random":
+        t_spin = time.perf_counter()
+        rew0, done0 = ex.slab(0)
+        while time.perf_counter() - t_spin < 0.3:
+            for _ in range(4):
+                env.rollout_into(tape[:K], rew0, done0, info, obs_slots)
+            torch.cuda.synchronize()
+    run(warmup, 0)
+    ex.drain()
+    reps_ms, span_ms, launches = [], [], []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for r in range(reps):
+        fence()
+        state["launches"] = 0
+        t0 = time.perf_counter()
+        ev0.record()
+        run(steps, warmup + r * steps)
+        ev1.record()
+        ex.drain()
+        fence()
+        el = time.perf_counter() - t0
+        if ctx.world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps_ms.append(el * 1e3)
+        span_ms.append(ev0.elapsed_time(ev1))     # hipEvents on the launch stream around the region's launches
+        launches.append(state["launches"])
+    out = {"scaling": scaling, "variant": variant, "envs_per_gpu": B, "envs_total": sum(counts), "chunk": K,
+           "obs_slots": R, "reps_ms": reps_ms, "median_ms": median(reps_ms),
+           "value": float(sum(counts)) * steps / (median(reps_ms) * 1e-3),
+           "ms_per_step": median(reps_ms) / steps,
+           "steps_per_launch": (steps / launches[0]) if launches[0] else 0.0,
+           "kernel": "uam_sweep_many_kernel (one launch per chunk)" if looped else "uam_sweep_kernel (one launch per step)",
+           "stream_span_ms_per_step": median(span_ms) / steps, "launches": launches[0],
+           "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives}
+    if want_bracketed and not looped and args.policy == "random":
+        # per-launch durations: a separate pass with hipEvents around each launch (serialises the queue slightly)
+        env.kernel_timing(True)
+        run(256, 0)
+        ex.drain()
+        _, sweep_ms, nsamp = env.kernel_timing_read()
+        env.kernel_timing(False)
+        out["bracketed_launch_ms"], out["sampled_launches"] = sweep_ms, nsamp
+    ex.drain()
+    torch.cuda.synchronize()
+    env.close()
+    del obs_slots, tape, info, ex
+    return out
 
-    # per-kernel durations: a separate pass with hipEvents around each launch (not part of `value`)
-    env.kernel_timing(True)
-    run(256, offset=args.warmup + args.steps)
-    drain()
-    own_ms, sweep_ms, nsamp = env.kernel_timing_read()
-    env.kernel_timing(False)
 
-    if rank == 0:
-        total_env_steps = float(B) * world * args.steps
-        value = total_env_steps / elapsed
-        step_bytes = env.step_bytes                      # (40 N + 150) B per env-step, SURVEY §8d
-        sweep_bytes = step_bytes                         # the step is one launch: it moves all of the step's bytes
-        # the hipEvents that bracket the timed region (divided by the launches) give the kernel's average duration
-        # without the perturbation of per-launch event records (`bracketed_launch_ms` is that perturbed figure)
-        dom_ms = kernel_ms
-        achieved = sweep_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc_path) and B == B_PER_GPU and N == N_INTRUDERS:
+def copy_ms(torch, dev, nbytes, iters):
+    """A plain device copy that moves `nbytes` in total (half read, half written): the practical HBM ceiling."""
+    n = (nbytes // 2) // 16 * 16
+    src = torch.empty((n,), dtype=torch.uint8, device=dev)
+    dst = torch.empty((n,), dtype=torch.uint8, device=dev)
+    src.zero_()
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def hbm_resident(ctx, args, variant):
+    """The same kernel at 1 M envs: 1.5 GB of algorithmic traffic per step, beyond the 256 MiB Infinity Cache."""
+    torch = ctx.torch
+    import uamenv
+    B, N = 1 << 20, args.intruders
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, rng=args.rng, precision=args.precision, seed=0,
+                                          auto_reset=True, device=ctx.local_rank)
+    dev = env.device
+    env.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    am = env.cfg.action_mode
+    if am == 2:
+        tape = torch.rand((8, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
+    else:
+        tape = torch.randint(0, 9 if am == 0 else 3, (8, B, 2) if am == 1 else (8, B), dtype=torch.int32, device=dev,
+                             generator=gen)
+    rew = torch.empty((8, B), dtype=torch.float32, device=dev)
+    done = torch.empty((8, B), dtype=torch.uint8, device=dev)
+    info = torch.empty((8, B), dtype=torch.uint8, device=dev)
+    for _ in range(4):
+        env.rollout_into(tape, rew, done, info)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times = []
+    for _ in range(5):
+        e0.record()
+        for _ in range(4):
+            env.rollout_into(tape, rew, done, info)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / 32)
+    ms = median(times)
+    nbytes = env.step_bytes
+    env.close()
+    del tape, rew, done, info
+    torch.cuda.empty_cache()
+    cms = copy_ms(torch, dev, nbytes, 10)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"envs": B, "bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+            "copy_same_bytes_ms": cms, "frac_of_copy": cms / ms, "launches_timed": 160,
+            "note": "hipEvents around 5 x 32 queued launches, median; working set 1.1 GB state+obs, not cache-resident"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    ctx = Ctx()
+    ctx.torch = torch
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if ctx.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ctx.world))
+    torch.cuda.set_device(ctx.local_rank)
+    ctx.dist = None
+    if ctx.world > 1:
+        import torch.distributed as dist
+        ctx.dist = dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", ctx.local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
+
+    primary = args.scaling
+    secondary = "strong" if primary == "weak" else "weak"
+    default_variant = {"weak": "discrete9", "strong": "continuous"}
+    pvar = args.variant or default_variant[primary]
+    res = measure(ctx, args, primary, pvar, args.steps, args.warmup, max(1, args.reps), want_bracketed=True)
+    sec = None
+    if not args.no_secondary:
+        sec = measure(ctx, args, secondary, default_variant[secondary], args.steps, args.warmup, max(1, min(3, args.reps)),
+                      want_bracketed=False)
+    resident = None
+    if ctx.world == 1 and not args.no_secondary and args.policy == "random":
+        try:
+            resident = hbm_resident(ctx, args, pvar)
+        except Exception as ex:       # an extra; must never take the measurement down
+            resident = {"error": repr(ex)}
+
+    if ctx.rank == 0:
+        N = args.intruders
+        spl = max(1.0, res["steps_per_launch"])
+        bytes_per_launch = res["step_bytes"] * spl
+        launch_ms = res["stream_span_ms_per_step"] * spl
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, PMC_PROFILE)
+        if os.path.exists(pmc_path) and res["envs_per_gpu"] == GLOBAL_BATCH and N == N_INTRUDERS and pvar == "discrete9":
             with open(pmc_path) as f:
                 traffic = json.load(f).get("uam_sweep_kernel", {}).get("hbm_bytes_per_launch")
+            traffic_src = PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE in its own run; not measured in this invocation)"
+        ccopy = copy_ms(torch, torch.device("cuda", ctx.local_rank), int(bytes_per_launch), 50) if ctx.world == 1 else None
+        workloads = {"weak": "SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU (BASELINE.json configs[2], "
+                             "roofline run)" % (args.batch, N),
+                     "strong": "SingleAircraft2Env continuous, ONE batch of %d envs x %d intruders partitioned over the "
+                               "GPUs (BASELINE.json configs[3])" % (args.batch, N)}
+        wl = workloads[primary] if pvar == default_variant[primary] else \
+            "%s variant, %s scaling, batch=%d x %d intruders" % (pvar, primary, args.batch, N)
         out = {
-            "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": ("SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU "
-                                    "(BASELINE.json configs[2], roofline run)" % (B, N)) if args.variant == "discrete9"
-                       else "%s variant, batch=%d x %d intruders per GPU" % (args.variant, B, N),
-                       "envs_per_gpu": B, "intruders": N, "policy": args.policy, "rng": args.rng,
-                       "variant": args.variant, "positions": "float32" if args.precision == "f32" else "float64 (exact promotion)", "obs": "float32[B,%d] written every step" % env.obs_dim,
-                       "exchange": "none" if world == 1 or args.exchange == "none" else
-                                   "one async %s of the [%d, B] reward+done slab per chunk, double-buffered "
-                                   "(overlaps the next chunk)" % (args.exchange, GATHER_EVERY)},
-            "pair_steps_per_sec": value * N,
+            "metric": "env_steps_per_sec", "value": res["value"], "unit": "env-steps/s", "n_gpus": ctx.world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": primary, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "envs_per_gpu": res["envs_per_gpu"], "envs_total": res["envs_total"],
+                       "intruders": N, "policy": args.policy, "rng": args.rng, "variant": pvar,
+                       "positions": "float32" if args.precision == "f32" else "float64 (exact promotion)",
+                       "obs": "float32[B,%d] written every step (%d slot%s)" % (res["obs_dim"], res["obs_slots"],
+                                                                                "" if res["obs_slots"] == 1 else "s"),
+                       "chunk": res["chunk"], "launch": res["kernel"],
+                       "exchange": "none" if ctx.world == 1 or args.exchange == "none" else
+                                   "one async %s of the [%d, B_local] reward+done slab per chunk, double-buffered "
+                                   "(overlaps the next chunk); %d per rank in a timed region"
+                                   % (args.exchange, res["chunk"], -(-args.steps // res["chunk"]))},
+            "reps_ms": res["reps_ms"], "timing": "median of %d repetitions of the %d-step region, each bracketed by "
+                                                 "barrier + synchronize, max over ranks" % (len(res["reps_ms"]), args.steps),
+            "pair_steps_per_sec": res["value"] * N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "uam_sweep_kernel (ownship phase + intruder sweep, one launch per step)",
-                         "bytes_per_launch": sweep_bytes,
-                         "avg_launch_ms": dom_ms, "bracketed_launch_ms": sweep_ms, "sampled_launches": nsamp,
-                         "own_kernel_avg_ms": own_ms,
-                         "whole_step": {"bytes": step_bytes, "avg_ms": kernel_ms,
-                                        "frac": step_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": res["kernel"], "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_ms": launch_ms,
+                         "avg_launch_ms_is": "hipEvent span of the timed region on the launch stream / launches: an upper "
+                                             "bound on the kernel's duration (includes inter-launch gaps%s)"
+                                             % (" and stream waits on the collective" if ctx.world > 1 else ""),
+                         "bracketed_launch_ms": res.get("bracketed_launch_ms"), "sampled_launches": res.get("sampled_launches"),
+                         "copy_same_bytes_ms": ccopy, "frac_of_copy": (ccopy / launch_ms) if ccopy else None,
+                         "hbm_resident": resident},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if sec is not None:
+            out[secondary] = {k: sec[k] for k in ("scaling", "variant", "envs_per_gpu", "envs_total", "chunk", "value",
+                                                  "ms_per_step", "reps_ms", "kernel", "steps_per_launch",
+                                                  "stream_span_ms_per_step")}
+            out[secondary]["workload"] = workloads[secondary]
+            sb = sec["step_bytes"] * max(1.0, sec["steps_per_launch"])
+            sms = sec["stream_span_ms_per_step"] * max(1.0, sec["steps_per_launch"])
+            out[secondary]["roofline_frac"] = sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if ctx.world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))
+                out["cpu_baseline"] = cpu_baseline(args.batch, N, min(16, len(os.sched_getaffinity(0))))
             except Exception as ex:   # the checker must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (ex,)}
         print(json.dumps(out))
-    env.close()
-    if world > 1:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -106,6 +106,8 @@ SYMBOLS = [
     ("uam_reset", C.c_int, [_P, _P, _P, _P]),
     ("uam_step", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("uam_step_many", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    ("uam_rollout", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    ("uam_steps_per_launch", C.c_int32, [_P, C.c_int32]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
     ("uam_nearest", C.c_int, [_P, _P, _P]),
@@ -133,11 +135,8 @@ SYMBOLS = [
 
 def build(force=False):
     """Compile csrc/libuamenv_hip.so for gfx950 with hipcc (works without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("uamenv.hip", "uam_device.h", "uam_pmath.h")]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "uamenv.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
-        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    # make knows every dependency (csrc/Makefile) and is a no-op when the library is up to date
+    subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
     return LIB_PATH
 
 

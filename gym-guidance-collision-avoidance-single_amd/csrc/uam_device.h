@@ -123,6 +123,8 @@ struct UamParams {
     const uint8_t* mask;
     int32_t many_K;               /* uam_sweep_many_kernel: steps per launch; actions / reward / done / info / noise advance by */
     int32_t act_step_words;       /* act_step_words 32-bit words resp. B elements per step */
+    int32_t obs_slots;            /* uam_sweep_many_kernel: 0 = only the last step emits the observation (into obs);
+                                     R > 0 = step k emits its observation into slot k % R of obs[R][B][D] (uam_rollout) */
     int32_t policy_kind;
     uint32_t policy_lo, policy_hi, policy_call;
     void* actions_out;
@@ -649,7 +651,7 @@ __device__ __forceinline__ void store_tail(const UamParams& p, float* dst, bool 
 }
 
 /* the wave streams its staged rows (LDS, final [env][D] layout) to HBM, 16 B per lane */
-__device__ __forceinline__ void obs_copy_out(const UamParams& p, const float* stage, int env_first, int lane)
+__device__ __forceinline__ void obs_copy_out(const UamParams& p, float* obs, const float* stage, int env_first, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -657,7 +659,7 @@ __device__ __forceinline__ void obs_copy_out(const UamParams& p, const float* st
     const int envs_per_wave = 64 >> p.lshift;
     const int nrows = min(envs_per_wave, p.B - env_first);
     const int chunks = nrows * (p.D >> 2);
-    float4* gdst = (float4*)(p.obs + (size_t)env_first * p.D);
+    float4* gdst = (float4*)(obs + (size_t)env_first * p.D);
     /* non-temporal: the observation is written once and never read back by the env, so it must not
      * evict the SoA state (re-read next step) from L2 / Infinity Cache: -8 % at 65536 envs, -16 % at 1 M */
     typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
@@ -728,7 +730,7 @@ __device__ __forceinline__ void knn_row(const UamParams& p, float* row, int gl, 
  * per lane (1 KiB per store instruction) — row-per-lane stores straight to HBM touch a different
  * 128-B line per lane and are store-issue bound.  stage = this wave's LDS region. */
 template <bool POS64, bool SH>
-__device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, int env_first, int g_in_wave,
+__device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* obs, float* stage, int env_first, int g_in_wave,
                                               int gl, bool env_ok, bool quad_ok, const Quad<POS64, SH>& q,
                                               const float* tail)
 {
@@ -737,9 +739,9 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* stage, 
         float* row = stage + (size_t)g_in_wave * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, true, min(4, p.N - 4 * gl), q);
         if (env_ok) store_tail(p, row + (size_t)p.N * p.obs_w, true, gl, tail);
-        obs_copy_out(p, stage, env_first, lane);
+        obs_copy_out(p, obs, stage, env_first, lane);
     } else if (env_ok) {
-        float* row = p.obs + (size_t)(env_first + g_in_wave) * p.D;
+        float* row = obs + (size_t)(env_first + g_in_wave) * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, false, min(4, p.N - 4 * gl), q);
         store_tail(p, row + (size_t)p.N * p.obs_w, false, gl, tail);
     }
@@ -754,9 +756,9 @@ __device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int e
     if (p.obs_mode == UAM_OBS_KNN5) {
         float* row = p.obs_vec ? stage + (size_t)g_in_wave * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
         knn_row<POS64, SH>(p, row, gl, p.L, env_ok, quad_ok, q, ox, oy, tail);
-        if (p.obs_vec) obs_copy_out(p, stage, env_first, threadIdx.x & 63);
+        if (p.obs_vec) obs_copy_out(p, p.obs, stage, env_first, threadIdx.x & 63);
     } else {
-        obs_pack_wave<POS64, SH>(p, stage, env_first, g_in_wave, gl, env_ok, quad_ok, q, tail);
+        obs_pack_wave<POS64, SH>(p, p.obs, stage, env_first, g_in_wave, gl, env_ok, quad_ok, q, tail);
     }
 }
 
@@ -928,9 +930,9 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
 #define UAM_MODE_KNN 4
 /* one step of the sweep for this block.  k = step within the launch (0 for uam_sweep_kernel; the loop index of
  * uam_sweep_many_kernel): the Philox step counter, the action / noise / reward / done / info rows advance with it;
- * with_obs = this step emits the observation. */
+ * obs_k = where this step emits its observation (nullptr: it does not). */
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false>
-__device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, const bool with_obs)
+__device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k)
 {
     typedef typename PosT<POS64>::type P;
     constexpr bool RI = (MODE & UAM_MODE_RI) != 0, SHAPED = (MODE & UAM_MODE_SHAPED) != 0, KNN = (MODE & UAM_MODE_KNN) != 0;
@@ -1205,14 +1207,14 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
-    if (with_obs && p.obs && !(UAM_ABLATE & 2)) {
+    if (obs_k && !(UAM_ABLATE & 2)) {
         float* stage = (float*)(lds_raw + (size_t)p.E * 48) + (size_t)wave_first_g * p.D;
         if constexpr (KNN) {
-            float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : p.obs + (size_t)(env_ok ? env : 0) * p.D;
+            float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : obs_k + (size_t)(env_ok ? env : 0) * p.D;
             knn_row<POS64, SH>(p, row, gl, L, env_ok, quad_ok, q, kx, ky, tail);
-            if (p.obs_vec) obs_copy_out(p, stage, env_first, tid & 63);
+            if (p.obs_vec) obs_copy_out(p, obs_k, stage, env_first, tid & 63);
         } else {
-            obs_pack_wave<POS64, SH>(p, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+            obs_pack_wave<POS64, SH>(p, obs_k, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
         }
     }
 }
@@ -1224,7 +1226,7 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* exact-promotion Philox instances: the fp64 spawn sits inside the respawn loop, and the SGPR-pinned sincos
      * flavour keeps its literals out of the VGPRs held across that loop (131 -> 91 VGPRs, -6 % step time).  The
      * RandIntruder and MT19937 instances measure slower with it (+3...16 %) and keep the plain flavour. */
-    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, true);
+    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, p.obs);
 }
 
 /* K consecutive steps in ONE launch (uam_step_many, Philox): envs never interact and a block only ever touches
@@ -1237,9 +1239,16 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_many_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int K = p.many_K;
+    const size_t slot_elems = (size_t)p.B * (size_t)p.D;
+    int slot = 0;
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        sweep_step<POS64, RNG, MODE, SH, ROS, true>(p, lds_raw, k, k == K - 1);
+        float* obs_k = nullptr;
+        if (p.obs) {
+            if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
+            else if (k == K - 1) obs_k = p.obs;
+        }
+        sweep_step<POS64, RNG, MODE, SH, ROS, true>(p, lds_raw, k, obs_k);
         __syncthreads();
     }
 }

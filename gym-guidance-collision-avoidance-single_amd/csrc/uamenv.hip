@@ -38,6 +38,7 @@ struct uam_env {
     uam_config cfg;
     int device;
     int Np, Q, L, lshift, T, E, D, hold_sh;
+    int num_cus;                /* compute units of the device (hipDeviceProp_t::multiProcessorCount) */
     uint32_t step_index;        /* uam_step calls so far */
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
     double2* noise_many;        /* [noise_many_cap][B] noise of one uam_step_many launch (grown on demand) */
@@ -255,9 +256,12 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (device_id < 0 || device_id >= ndev) return fail(UAM_ENODEV, "device_id %d out of range (0..%d)", device_id, ndev - 1);
     HIP_TRY(hipSetDevice(device_id));
 
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     uam_env* e = new uam_env();
     e->cfg = *cfg;
     e->device = device_id;
+    e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->timing = false;
     e->timed_launches = 0;
     e->policy_calls = 0;
@@ -459,7 +463,7 @@ static bool many_supported(const uam_env* e)
 {
     /* the looped kernel holds 115-166 VGPRs (3 waves/SIMD at worst = 3 of these 4-wave blocks per CU): it only pays
      * while the whole grid is resident in one round — which is exactly the launch-bound small-batch regime */
-    const int resident_blocks = 256 * 3 * 256 / e->T;
+    const int resident_blocks = e->num_cus * 3 * 256 / e->T;
     return e->cfg.rng_mode == UAM_RNG_PHILOX && e->cfg.precision == UAM_POS_F32 &&
            !(e->cfg.shaped_reward && e->hold_sh) && !e->ktiming &&
            grid_of(e) <= resident_blocks;
@@ -569,15 +573,24 @@ extern "C" int uam_step(uam_env* e, const void* actions, float* obs_out, float* 
     return step_once(e, actions, obs_out, reward_out, done_out, info_out, (hipStream_t)stream);
 }
 
-extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,
-                             uint8_t* done_out, uint8_t* info_out, void* stream)
+/* K steps from an action tape.  obs_slots = 0: obs_out (may be NULL) receives the observation after the last step;
+ * obs_slots = R > 0: step k writes its observation into slot k % R of obs_out[R][B][D]. */
+static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float* obs_out, int32_t obs_slots,
+                          float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream)
 {
     int rc = check_step_args(e, action_tape, reward_out, done_out);
     if (rc) return rc;
     if (K < 1) return fail(UAM_EINVAL, "K must be >= 1 (got %d)", K);
+    if (obs_slots < 0) return fail(UAM_EINVAL, "obs_slots must be >= 0 (got %d)", obs_slots);
+    if (obs_slots > 0 && !obs_out) return fail(UAM_EINVAL, "obs_slots > 0 needs obs_out");
     HIP_TRY(hipSetDevice(e->device));
     const size_t B = (size_t)e->cfg.num_envs;
     const size_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    const size_t slot_elems = B * (size_t)e->D;
+    if (obs_slots > 0 && ((slot_elems * 4) & 15u) && e->D % 4 == 0 && (((uintptr_t)obs_out & 15u) == 0)) {
+        /* slots after the first would lose the 16-byte alignment the staged obs path was chosen for */
+        return fail(UAM_EINVAL, "obs slot size B*D*4 = %zu bytes is not a multiple of 16", slot_elems * 4);
+    }
     if (K > 1 && many_supported(e)) {
         /* one launch for all K steps (uam_sweep_many_kernel); the noise of exactly these steps is drawn first */
         hipStream_t st = (hipStream_t)stream;
@@ -607,6 +620,7 @@ extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, flo
         p.noise = e->noise_many;
         p.actions = action_tape; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
         p.many_K = K;
+        p.obs_slots = obs_slots;
         p.act_step_words = (int32_t)(B * abytes / 4);
         launch_many(e, p, st);
         HIP_TRY(hipGetLastError());
@@ -616,11 +630,31 @@ extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, flo
     }
     for (int k = 0; k < K; k++) {
         const void* a = (const char*)action_tape + (size_t)k * B * abytes;
-        rc = step_once(e, a, k == K - 1 ? obs_out : nullptr, reward_out + (size_t)k * B, done_out + (size_t)k * B,
+        float* ob = obs_slots > 0 ? obs_out + (size_t)(k % obs_slots) * slot_elems : (k == K - 1 ? obs_out : nullptr);
+        rc = step_once(e, a, ob, reward_out + (size_t)k * B, done_out + (size_t)k * B,
                        info_out ? info_out + (size_t)k * B : nullptr, (hipStream_t)stream);
         if (rc) return rc;
     }
     return UAM_OK;
+}
+
+extern "C" int32_t uam_steps_per_launch(const uam_env* e, int32_t K)
+{
+    if (!e || K < 1) return 0;
+    return (K > 1 && many_supported(e)) ? K : 1;
+}
+
+extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,
+                             uint8_t* done_out, uint8_t* info_out, void* stream)
+{
+    return step_many_impl(e, K, action_tape, obs_out, 0, reward_out, done_out, info_out, stream);
+}
+
+extern "C" int uam_rollout(uam_env* e, int32_t K, const void* action_tape, float* obs_slots_out, int32_t obs_slots,
+                           float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream)
+{
+    if (obs_slots < 1) return fail(UAM_EINVAL, "uam_rollout needs obs_slots >= 1 (got %d)", obs_slots);
+    return step_many_impl(e, K, action_tape, obs_slots_out, obs_slots, reward_out, done_out, info_out, stream);
 }
 
 extern "C" int uam_observe(uam_env* e, float* obs_out, void* stream)

@@ -299,6 +299,37 @@ class BatchedSingleAircraftEnv:
                                            rew.data_ptr(), done.data_ptr(), info.data_ptr(), self._stream()))
         return self._obs, rew, done, info
 
+    def rollout_into(self, action_tape, rew_out, done_out, info_out=None, obs_out=None):
+        """K steps from a device action tape [K, B(,2)] in ONE C call (uam_rollout) that keeps every step's
+        observation: rewards / dones / info codes go to caller-owned device slabs [K, B]; step k's observation goes
+        to slot k % R of `obs_out` (float32[R, B, D]; default: the env's own [B, D] buffer, R = 1).  The open-loop
+        rollout of baselines/ppo2/runner.py:26-38 with the actions already on the device.  Returns obs_out."""
+        torch = self._torch
+        am = self.cfg.action_mode
+        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        K = int(action_tape.shape[0])
+        if action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous() \
+                or action_tape.numel() != K * self._act_numel:
+            raise ValueError("action tape must be a contiguous device tensor [K, B(,2)] of %s" % dt)
+        for t, tdt in ((rew_out, torch.float32), (done_out, torch.uint8), (info_out, torch.uint8)):
+            if t is not None and (t.dtype != tdt or t.numel() != K * self.num_envs or not t.is_contiguous()
+                                  or t.device != self.device):
+                raise ValueError("rollout slabs must be contiguous device tensors [K, B]")
+        if obs_out is None:
+            obs_out = self._obs.view(1, self.num_envs, self.obs_dim)
+        if obs_out.dtype != torch.float32 or obs_out.dim() != 3 or tuple(obs_out.shape[1:]) != (self.num_envs, self.obs_dim) \
+                or not obs_out.is_contiguous() or obs_out.device != self.device:
+            raise ValueError("obs_out must be a contiguous device tensor float32[R, B, D]")
+        capi.check(self._lib.uam_rollout(self._h, K, action_tape.data_ptr(), obs_out.data_ptr(), int(obs_out.shape[0]),
+                                         rew_out.data_ptr(), done_out.data_ptr(),
+                                         None if info_out is None else info_out.data_ptr(), self._stream()))
+        self._keep = action_tape
+        return obs_out
+
+    def steps_per_launch(self, K):
+        """K if a chunk of K steps runs as one launch of the looped kernel on this handle, else 1."""
+        return int(self._lib.uam_steps_per_launch(self._h, int(K)))
+
     def observe(self):
         capi.check(self._lib.uam_observe(self._h, self._obs.data_ptr(), self._stream()))
         return self._obs

@@ -22,6 +22,89 @@ def shard_bounds(global_envs, world_size, rank):
     return first, count
 
 
+class RolloutExchange:
+    """The one exchange of the sharded path: per rollout chunk of K steps, the rank's `[K, B_slab]`
+    reward (float32) and done (uint8) slabs leave in ONE collective.  Both live in one byte buffer, so a single
+    all-gather (or gather to rank 0) moves them; two slabs alternate, so the collective of chunk c runs on the
+    backend's own stream / thread while chunk c+1 steps into the other slab.
+
+    Every rank contributes the same number of bytes, sized for the widest shard (`max(counts)`); a narrower
+    rank's `[K, count]` slabs are contiguous at the front of their halves and the tail is padding.  Works on device tensors over RCCL
+    (backend "nccl") and on CPU tensors over gloo (the world_size-2 tests).  This is the object `bench.py` steps
+    into, and the parallel step of baselines/common/vec_env/subproc_vec_env.py:63-74 (`step_wait`: one result per
+    worker, stacked) turned inside out: state never moves, only 5 bytes per env-step do."""
+
+    def __init__(self, dist, K, counts, rank, device, mode="all_gather"):
+        import torch
+        if mode not in ("all_gather", "gather", "none"):
+            raise ValueError("mode must be all_gather, gather or none")
+        self.dist, self.K, self.counts, self.rank, self.mode = dist, int(K), list(counts), int(rank), mode
+        self.world = len(self.counts)
+        self.B_slab = max(self.counts)
+        self.count = self.counts[self.rank]
+        KB = (self.K * self.B_slab + 15) & ~15     # float32 views of every rank's segment stay 4-byte aligned
+        self._KB = KB
+
+        def make():
+            raw = torch.zeros((KB * 5,), dtype=torch.uint8, device=device)
+            n = self.K * self.count
+            return (raw, raw[:n * 4].view(torch.float32).view(self.K, self.count),
+                    raw[KB * 4:KB * 4 + n].view(self.K, self.count))
+
+        self._slabs = [make(), make()]
+        self._pending = [None, None]
+        receives = self.world > 1 and (mode == "all_gather" or (mode == "gather" and self.rank == 0))
+        self._gathered = [torch.zeros((self.world * KB * 5,), dtype=torch.uint8, device=device) for _ in range(2)] \
+            if receives else None
+        self.collectives = 0
+
+    def slab(self, c):
+        """(reward float32[K, count], done uint8[K, count]) contiguous views of slab c (0/1)."""
+        _, rew, done = self._slabs[c & 1]
+        return rew, done
+
+    def begin(self, c):
+        """Before stepping into slab c: its previous collective must have read it (stream-ordered on the device —
+        the host does not block with RCCL)."""
+        w = self._pending[c & 1]
+        if w is not None:
+            w.wait()
+            self._pending[c & 1] = None
+
+    def exchange(self, c):
+        """Start the collective of slab c (asynchronous)."""
+        if self.world == 1 or self.mode == "none":
+            return
+        raw = self._slabs[c & 1][0]
+        if self.mode == "all_gather":
+            self._pending[c & 1] = self.dist.all_gather_into_tensor(self._gathered[c & 1], raw, async_op=True)
+        else:
+            outs = list(self._gathered[c & 1].view(self.world, -1).unbind(0)) if self.rank == 0 else None
+            self._pending[c & 1] = self.dist.gather(raw, gather_list=outs, dst=0, async_op=True)
+        self.collectives += 1
+
+    def drain(self):
+        for c in (0, 1):
+            self.begin(c)
+
+    def gathered(self, c, k=None):
+        """After `begin(c)` / `drain()`: (rewards float32[k, global_envs], dones uint8[k, global_envs]) of the chunk
+        last exchanged from slab c, ranks concatenated in global env order (padding columns dropped)."""
+        import torch
+        k = self.K if k is None else int(k)
+        if self.world == 1 or self.mode == "none":
+            rew, done = self.slab(c)
+            return rew[:k], done[:k]
+        if self._gathered is None:
+            raise RuntimeError("this rank receives nothing in mode %r" % self.mode)
+        g = self._gathered[c & 1].view(self.world, self._KB * 5)
+        rews, dones = [], []
+        for r, n in enumerate(self.counts):
+            rews.append(g[r, :self.K * n * 4].view(torch.float32).view(self.K, n)[:k])
+            dones.append(g[r, self._KB * 4:self._KB * 4 + self.K * n].view(self.K, n)[:k])
+        return torch.cat(rews, dim=1), torch.cat(dones, dim=1)
+
+
 class ShardedSingleAircraftEnv:
     """VecEnv-shaped front end of this rank's shard + chunked all-gather of rewards/dones.
 

@@ -207,6 +207,20 @@ int uam_step(uam_env* env, const void* actions, float* obs_out, float* reward_ou
 int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_out,
                   float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
 
+/* uam_step_many that keeps EVERY step's observation: step k writes its observation into slot k % obs_slots of
+ * obs_slots_out = float32[obs_slots][B][D] (device).  obs_slots = K gives the rollout slab a learner stores
+ * (mb_obs of Algorithms/baselines-master/baselines/ppo2/runner.py:26-38, a2c/runner.py:20-37); obs_slots = 2 is the
+ * double buffer of an acting loop; obs_slots = 1 overwrites one [B, D] buffer as K uam_step calls with the same
+ * obs_out would.  B*D*4 must be a multiple of 16 when obs_slots_out is 16-byte aligned and D % 4 == 0 (every
+ * slot then keeps the alignment of the wide-store path).  Everything else as uam_step_many, including the
+ * single-launch form for small batches. */
+int uam_rollout(uam_env* env, int32_t K, const void* action_tape, float* obs_slots_out, int32_t obs_slots,
+                float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
+
+/* How uam_step_many / uam_rollout would run a chunk of K steps on this handle: K when all of them go into one
+ * launch of the looped kernel, 1 when K single-step launches are queued (0 on a bad argument). */
+int32_t uam_steps_per_launch(const uam_env* env, int32_t K);
+
 /* Write the current observation of every env without stepping. */
 int uam_observe(uam_env* env, float* obs_out, void* stream);
 

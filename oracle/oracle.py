@@ -118,9 +118,8 @@ def make_view(st, B, N):
 
 def build(force=False):
     """Compile oracle/_build/liboracle.so with the committed Makefile (gcc)."""
-    src = os.path.join(_HERE, "uam_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    # make knows every dependency (oracle/Makefile: the .c, its header and the product's portable-math headers)
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 

@@ -27,3 +27,9 @@ def test_bench_prints_one_contract_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
     assert abs(d["value"] - 4096 * 60 / (d["ms_per_step"] * 1e-3 * 60)) / d["value"] < 1e-6
+    # median of the listed repetitions; the second workload and the 1 M-env roofline pass ride in the same line
+    reps = sorted(d["reps_ms"])
+    assert len(reps) == 5 and abs(d["ms_per_step"] * 60 - reps[2]) < 1e-9
+    assert d["strong"]["variant"] == "continuous" and d["strong"]["envs_total"] == 4096 and d["strong"]["value"] > 0
+    hr = r["hbm_resident"]
+    assert hr["envs"] == 1 << 20 and 0 < hr["frac"] < 1 and hr["copy_same_bytes_ms"] > 0

@@ -1,0 +1,103 @@
+"""uam_rollout (every step's observation kept, chunk of K steps per C call) and bench.py's own multi-rank path
+on the GPU box: two gloo ranks sharing cuda:0, started by bench.py itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity_util as pu  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def uamenv():
+    import uamenv as u
+    u.build()
+    return u
+
+
+@pytest.mark.parametrize("variant,B,N,K,R,looped", [
+    ("discrete9", 4096, 8, 7, 7, True),        # looped kernel, full rollout slab
+    ("continuous", 8192, 32, 12, 2, True),     # BASELINE config 4's per-GPU shard at N=8: looped kernel, double buffer
+    ("randintruder", 512, 64, 5, 1, True),     # one buffer overwritten every step
+    ("her9", 700, 20, 9, 4, True),
+    ("discrete9", 32768, 32, 5, 3, False),     # grid larger than one resident round: K queued single-step launches
+    ("discrete9", 300, 5, 6, 6, True),         # D = 28: 16-byte aligned rows only every 4th env
+])
+def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
+    """Slot k % R of the rollout's obs buffer must hold exactly what uam_step would have returned at step k, and
+    rewards / dones / infos / state must equal K separate steps bit for bit."""
+    import torch
+    a = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=21)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=21)
+    a.reset(); b.reset()
+    dev = a.device
+    assert (a.steps_per_launch(K) == K) == looped, "unexpected launch form"
+    for rep in range(2):
+        tape = torch.stack([a.policy_actions("goal" if rep else "random", seed=rep * 50 + k) for k in range(K)]).contiguous()
+        obs = torch.full((R, B, a.obs_dim), float("nan"), dtype=torch.float32, device=dev)
+        rew = torch.empty((K, B), dtype=torch.float32, device=dev)
+        done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        a.rollout_into(tape, rew, done, info, obs)
+        want = {}
+        for k in range(K):
+            o, r, d, i = b.step(tape[k])
+            assert torch.equal(rew[k], r) and torch.equal(done[k], d.view(torch.uint8)) and torch.equal(info[k], i.codes), (rep, k)
+            want[k % R] = o.clone()
+        for slot, o in want.items():
+            assert torch.equal(obs[slot], o), (rep, slot)
+        pu.compare_states(a.get_state(), b.get_state(), "after rollout rep %d" % rep, hold_sh=variant == "randintruder")
+    a.close(); b.close()
+
+
+def test_rollout_rejects_bad_arguments(uamenv):
+    import torch
+    from uamenv import _capi as capi
+    env = uamenv.BatchedSingleAircraftEnv(64, 8)
+    env.reset()
+    dev = env.device
+    tape = torch.zeros((4, 64), dtype=torch.int32, device=dev)
+    rew = torch.empty((4, 64), dtype=torch.float32, device=dev)
+    done = torch.empty((4, 64), dtype=torch.uint8, device=dev)
+    obs = torch.empty((2, 64, env.obs_dim), dtype=torch.float32, device=dev)
+    L = capi.lib()
+    assert L.uam_rollout(env._h, 4, tape.data_ptr(), obs.data_ptr(), 0, rew.data_ptr(), done.data_ptr(), None, None) == -22
+    assert L.uam_rollout(env._h, 4, tape.data_ptr(), None, 2, rew.data_ptr(), done.data_ptr(), None, None) == -22
+    assert L.uam_rollout(env._h, 0, tape.data_ptr(), obs.data_ptr(), 2, rew.data_ptr(), done.data_ptr(), None, None) == -22
+    assert L.uam_steps_per_launch(env._h, 0) == 0 and L.uam_steps_per_launch(env._h, 1) == 1
+    with pytest.raises(ValueError):
+        env.rollout_into(tape, rew, done, None, obs[:, :32])
+    env.close()
+
+
+def _run_bench(extra, timeout=300):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
+    """`bench.py --gpus 2` with no rendezvous in the environment: it must start its two ranks itself (gloo, both on
+    cuda:0 — the box has one GPU), step each rank's shard in chunks through uam_rollout, exchange one slab per
+    chunk and print ONE line whose strong-scaling field partitions the batch."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    d = _run_bench(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "70", "--warmup", "10", "--reps", "2",
+                    "--batch", "8192", "--intruders", "8", "--chunk", "32", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["steps"] == 70 and d["scaling"] == "weak"
+    assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["envs_total"] == 16384
+    assert len(d["reps_ms"]) == 2 and d["ms_per_step"] > 0
+    assert abs(d["value"] - 16384 * 70 / (d["ms_per_step"] * 70e-3)) / d["value"] < 1e-9
+    assert "all_gather" in d["config"]["exchange"] and "3 per rank" in d["config"]["exchange"]     # ceil(70 / 32)
+    s = d["strong"]
+    assert s["scaling"] == "strong" and s["variant"] == "continuous" and s["envs_per_gpu"] == 4096 and s["envs_total"] == 8192
+    assert s["value"] > 0 and "cpu_baseline" not in d

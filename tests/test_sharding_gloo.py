@@ -96,3 +96,103 @@ def test_shard_bounds_partition():
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     with pytest.raises(ValueError):
         shard_bounds(8, 2, 2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's own N>1 path: RolloutExchange (double-buffered [K, B_local] reward/done slabs, ONE collective per
+# chunk).  On CPU the slabs are filled by the oracle instead of uam_rollout; everything else — slab layout, the
+# alternation, begin/exchange/drain ordering, partial chunks, uneven shards, gather-to-rank-0 — is the code the
+# 8-GPU run executes.
+def _exchange_worker(rank, world, port, G, N, T, K, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uamenv.sharded import RolloutExchange, shard_bounds
+    spans = [shard_bounds(G, world, r) for r in range(world)]
+    counts = [c for _, c in spans]
+    first, count = spans[rank]
+    env = OracleStepper(count, N, first, seed=31)
+    env.reset()
+    rs = np.random.RandomState(9)
+    acts = rs.randint(0, 9, size=(T, G)).astype(np.int32)
+    ex = RolloutExchange(dist, K, counts, rank, torch.device("cpu"), mode=mode)
+    got_r, got_d, chunks = [], [], []
+    t, c = 0, 0
+    while t < T:
+        k = min(K, T - t)
+        ex.begin(c)
+        if c >= 2 and (mode == "all_gather" or rank == 0):      # slab c was exchanged two chunks ago: read it before reuse
+            r, d = ex.gathered(c, chunks[c - 2])
+            got_r.append(r.clone().numpy()); got_d.append(d.clone().numpy())
+        rew, done = ex.slab(c)
+        assert rew.shape == (K, count) and rew.is_contiguous() and done.is_contiguous()
+        for j in range(k):
+            _, r_, d_, _ = env.step(acts[t + j, first:first + count])
+            rew[j].copy_(r_)
+            done[j].copy_(d_.to(torch.uint8))
+        ex.exchange(c)
+        chunks.append(k)
+        t += k
+        c += 1
+    ex.drain()
+    if mode == "all_gather" or rank == 0:
+        for cc in range(max(0, c - 2), c):
+            r, d = ex.gathered(cc, chunks[cc])
+            got_r.append(r.clone().numpy()); got_d.append(d.clone().numpy())
+        np.savez(os.path.join(out_dir, "x%d.npz" % rank), rew=np.concatenate(got_r), done=np.concatenate(got_d))
+    assert ex.collectives == c
+    env.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G,mode", [(64, "all_gather"), (37, "all_gather"), (37, "gather")])
+def test_rollout_exchange_two_ranks_equal_one_batch(tmp_path, G, mode):
+    N, T, K, world = 8, 50, 16, 2         # 50 = 3 full chunks + a partial one of 2 steps
+    port = 29950 + (os.getpid() % 300) + G + (7 if mode == "gather" else 0)
+    mp.spawn(_exchange_worker, args=(world, port, G, N, T, K, mode, str(tmp_path)), nprocs=world, join=True)
+    whole = OracleStepper(G, N, 0, seed=31)
+    whole.reset()
+    rs = np.random.RandomState(9)
+    acts = rs.randint(0, 9, size=(T, G)).astype(np.int32)
+    rew, done = [], []
+    for t in range(T):
+        _, r, d, _ = whole.step(acts[t])
+        rew.append(r.numpy()); done.append(d.numpy())
+    rew, done = np.stack(rew), np.stack(done).astype(np.uint8)
+    receivers = range(world) if mode == "all_gather" else [0]
+    for r in receivers:
+        o = np.load(os.path.join(str(tmp_path), "x%d.npz" % r))
+        assert o["rew"].shape == (T, G)
+        assert np.array_equal(o["rew"], rew) and np.array_equal(o["done"], done)
+    if mode == "gather":
+        assert not os.path.exists(os.path.join(str(tmp_path), "x1.npz"))
+
+
+def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE must start torch.distributed.run as a CHILD and must not have
+    imported torch (let alone touched the GPU) in the parent."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    import bench
+    importlib.reload(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        seen["env"] = env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7                                     # the child's status is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def parse_args")]
+    assert "import torch" not in head and "import uamenv" not in head   # nothing GPU-capable at module import
