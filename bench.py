@@ -134,7 +134,7 @@ def median(xs):
     return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
 
 
-def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed):
+def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fuse="auto"):
     """One workload on this rank's shard: spin-up, `warmup` untimed steps, then `reps` repetitions of exactly `steps`
     steps, each bracketed by barrier + synchronize; max over ranks per repetition."""
     torch, dist = ctx.torch, ctx.dist
@@ -152,7 +152,7 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed):
     B = counts[ctx.rank]
     K = args.chunk if args.chunk > 0 else max(32, min(256, 32 * GLOBAL_BATCH // max(B, 1)))
     env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, rng=args.rng, precision=args.precision, seed=0,
-                                          auto_reset=True, device=ctx.local_rank, env_id_offset=first)
+                                          auto_reset=True, device=ctx.local_rank, env_id_offset=first, fuse_rollout=fuse)
     dev = env.device
     env.reset()
     gen = torch.Generator(device=dev)
@@ -238,7 +238,10 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed):
            "steps_per_launch": (steps / launches[0]) if launches[0] else 0.0,
            "kernel": "uam_sweep_many_kernel (one launch per chunk)" if looped else "uam_sweep_kernel (one launch per step)",
            "stream_span_ms_per_step": median(span_ms) / steps, "launches": launches[0],
-           "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives}
+           "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives,
+           # algorithmic bytes of one launch: a step's bytes for the step kernel; for the looped kernel (state in
+           # registers for the whole launch) the state once + K x the step's outputs and inputs
+           "launch_bytes": env.rollout_bytes(K) if looped else env.step_bytes, "fuse": fuse}
     if want_bracketed and not looped and args.policy == "random":
         # per-launch durations: a separate pass with hipEvents around each launch (serialises the queue slightly)
         env.kernel_timing(True)
@@ -348,6 +351,12 @@ def main():
     if not args.no_secondary:
         sec = measure(ctx, args, secondary, default_variant[secondary], args.steps, args.warmup, max(1, min(3, args.reps)),
                       want_bracketed=False)
+    fused = None
+    if ctx.world == 1 and not args.no_secondary and args.policy == "random":
+        # the same workload with the chunk FUSED into one looped launch per chunk (fuse_rollout = always): open-loop
+        # only, state register-resident for the whole chunk — reported beside `value`, never as `value`
+        fused = measure(ctx, args, primary, pvar, args.steps, args.warmup, max(1, min(3, args.reps)), want_bracketed=False,
+                        fuse="always")
     resident = None
     if ctx.world == 1 and not args.no_secondary and args.policy == "random":
         try:
@@ -358,7 +367,7 @@ def main():
     if ctx.rank == 0:
         N = args.intruders
         spl = max(1.0, res["steps_per_launch"])
-        bytes_per_launch = res["step_bytes"] * spl
+        bytes_per_launch = float(res["launch_bytes"])
         launch_ms = res["stream_span_ms_per_step"] * spl
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
@@ -407,9 +416,19 @@ def main():
                                                   "ms_per_step", "reps_ms", "kernel", "steps_per_launch",
                                                   "stream_span_ms_per_step")}
             out[secondary]["workload"] = workloads[secondary]
-            sb = sec["step_bytes"] * max(1.0, sec["steps_per_launch"])
             sms = sec["stream_span_ms_per_step"] * max(1.0, sec["steps_per_launch"])
-            out[secondary]["roofline_frac"] = sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out[secondary]["launch_bytes"] = sec["launch_bytes"]
+            out[secondary]["roofline_frac"] = sec["launch_bytes"] / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if fused is not None:
+            fms = fused["stream_span_ms_per_step"] * max(1.0, fused["steps_per_launch"])
+            out["fused_rollout"] = {k: fused[k] for k in ("value", "ms_per_step", "reps_ms", "kernel", "steps_per_launch",
+                                                          "chunk", "launch_bytes")}
+            out["fused_rollout"]["roofline_frac"] = fused["launch_bytes"] / (fms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["fused_rollout"]["note"] = ("same workload, each chunk of %d steps fused into ONE launch of the looped kernel "
+                                            "(uam_config.fuse_rollout = always): open-loop action tape only; env state stays in "
+                                            "registers for the chunk, so a step moves %d B/env instead of %d"
+                                            % (fused["chunk"], fused["launch_bytes"] // (fused["chunk"] * res["envs_per_gpu"]),
+                                               res["step_bytes"] // res["envs_per_gpu"]))
         if ctx.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.batch, N, min(16, len(os.sched_getaffinity(0))))

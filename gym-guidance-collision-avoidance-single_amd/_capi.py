@@ -46,7 +46,7 @@ class UamConfig(C.Structure):
         ("own_x0", C.c_double), ("own_y0", C.c_double), ("own_speed0", C.c_double), ("own_heading0", C.c_double),
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
         ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
-        ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("reserved1", C.c_int32),
+        ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("fuse_rollout", C.c_int32),
     ]
 
 
@@ -118,6 +118,7 @@ SYMBOLS = [
     ("uam_set_state", C.c_int, [_P, C.POINTER(UamStateView)]),
     ("uam_policy", C.c_int, [_P, C.c_int32, C.c_uint64, _P, _P]),
     ("uam_step_bytes", C.c_int64, [_P]),
+    ("uam_rollout_bytes", C.c_int64, [_P, C.c_int32]),
     ("uam_timing_begin", C.c_int, [_P, _P]),
     ("uam_timing_end", C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     ("uam_kernel_timing", C.c_int, [_P, C.c_int32]),

@@ -39,6 +39,21 @@
 #ifndef UAM_ABLATE
 #define UAM_ABLATE 0   /* development-only ablation mask (tools/ablate.py); 0 in every shipped build */
 #endif
+#ifndef UAM_PHILOX_WIDE
+#define UAM_PHILOX_WIDE 0   /* 1: 64-bit products in Philox (fewer quarter-rate multiplies, more VGPRs: 63 -> 71 in the step kernel) */
+#endif
+/* development-only phase timing of the looped kernel (tools/stamp_many.py): -DUAM_STAMP=1 makes every sweeping
+ * wave accumulate s_memtime deltas per phase of sweep_step and write them to the buffer passed as actions_out */
+#ifndef UAM_STAMP
+#define UAM_STAMP 0
+#endif
+#if UAM_STAMP
+#define UAM_NSTAMP 10
+#define UAM_STAMP_AT(i) do { if constexpr (PERSIST) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define UAM_STAMP_AT(i) do { } while (0)
+#endif
 #define UAM_MT_N 624
 #define UAM_MT_M 397
 #define UAM_MAX_BLOCK 512
@@ -51,6 +66,13 @@
 #define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_num_sgpr(UAM_SGPR_CAP)))
 #else
 #define UAM_STEP_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_STEP_WAVES_PER_EU, 8)))
+#endif
+
+/* the looped kernel: development builds may force an occupancy (-DUAM_MANY_WAVES_PER_EU=4: 128 VGPRs + spills) */
+#if defined(UAM_MANY_WAVES_PER_EU)
+#define UAM_MANY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_MANY_WAVES_PER_EU, 8)))
+#else
+#define UAM_MANY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK)
 #endif
 
 /* device pointers of the struct-of-arrays env state (HBM) */
@@ -123,6 +145,7 @@ struct UamParams {
     const uint8_t* mask;
     int32_t many_K;               /* uam_sweep_many_kernel: steps per launch; actions / reward / done / info / noise advance by */
     int32_t act_step_words;       /* act_step_words 32-bit words resp. B elements per step */
+    int32_t obs_direct;           /* uam_sweep_many_kernel: 1 = rows leave straight from registers (no LDS staging) */
     int32_t obs_slots;            /* uam_sweep_many_kernel: 0 = only the last step emits the observation (into obs);
                                      R > 0 = step k emits its observation into slot k % R of obs[R][B][D] (uam_rollout) */
     int32_t policy_kind;
@@ -151,8 +174,15 @@ __device__ __forceinline__ void uam_philox(uint32_t c0, uint32_t c1, uint32_t c2
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
+#if UAM_PHILOX_WIDE
+        /* one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair */
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#else
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#endif
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
@@ -651,6 +681,7 @@ __device__ __forceinline__ void store_tail(const UamParams& p, float* dst, bool 
 }
 
 /* the wave streams its staged rows (LDS, final [env][D] layout) to HBM, 16 B per lane */
+template <bool DEEP = false>
 __device__ __forceinline__ void obs_copy_out(const UamParams& p, float* obs, const float* stage, int env_first, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -663,8 +694,24 @@ __device__ __forceinline__ void obs_copy_out(const UamParams& p, float* obs, con
     /* non-temporal: the observation is written once and never read back by the env, so it must not
      * evict the SoA state (re-read next step) from L2 / Infinity Cache: -8 % at 65536 envs, -16 % at 1 M */
     typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
-    for (int c = lane; c < chunks; c += 64)
-        __builtin_nontemporal_store(((const uam_f32x4*)stage)[c], &((uam_f32x4*)gdst)[c]);
+    if constexpr (DEEP) {
+        /* looped kernel at one or two waves per SIMD: nothing else hides the LDS latency, so four reads are in
+         * flight before the first store instead of one read -> wait -> store per iteration */
+        for (int c = lane; c < chunks; c += 256) {
+            const bool k1 = c + 64 < chunks, k2 = c + 128 < chunks, k3 = c + 192 < chunks;
+            const uam_f32x4 v0 = ((const uam_f32x4*)stage)[c];
+            const uam_f32x4 v1 = ((const uam_f32x4*)stage)[k1 ? c + 64 : c];
+            const uam_f32x4 v2 = ((const uam_f32x4*)stage)[k2 ? c + 128 : c];
+            const uam_f32x4 v3 = ((const uam_f32x4*)stage)[k3 ? c + 192 : c];
+            __builtin_nontemporal_store(v0, &((uam_f32x4*)gdst)[c]);
+            if (k1) __builtin_nontemporal_store(v1, &((uam_f32x4*)gdst)[c + 64]);
+            if (k2) __builtin_nontemporal_store(v2, &((uam_f32x4*)gdst)[c + 128]);
+            if (k3) __builtin_nontemporal_store(v3, &((uam_f32x4*)gdst)[c + 192]);
+        }
+    } else {
+        for (int c = lane; c < chunks; c += 64)
+            __builtin_nontemporal_store(((const uam_f32x4*)stage)[c], &((uam_f32x4*)gdst)[c]);
+    }
 }
 
 /* UAM_OBS_KNN5 row of one env, built by its lane group from the quads in registers:
@@ -729,7 +776,7 @@ __device__ __forceinline__ void knn_row(const UamParams& p, float* row, int gl, 
  * the final [env][D] layout, then the wave streams its contiguous span of rows to HBM with 16 B
  * per lane (1 KiB per store instruction) — row-per-lane stores straight to HBM touch a different
  * 128-B line per lane and are store-issue bound.  stage = this wave's LDS region. */
-template <bool POS64, bool SH>
+template <bool POS64, bool SH, bool DEEP = false>
 __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* obs, float* stage, int env_first, int g_in_wave,
                                               int gl, bool env_ok, bool quad_ok, const Quad<POS64, SH>& q,
                                               const float* tail)
@@ -739,7 +786,7 @@ __device__ __forceinline__ void obs_pack_wave(const UamParams& p, float* obs, fl
         float* row = stage + (size_t)g_in_wave * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, true, min(4, p.N - 4 * gl), q);
         if (env_ok) store_tail(p, row + (size_t)p.N * p.obs_w, true, gl, tail);
-        obs_copy_out(p, obs, stage, env_first, lane);
+        obs_copy_out<DEEP>(p, obs, stage, env_first, lane);
     } else if (env_ok) {
         float* row = obs + (size_t)(env_first + g_in_wave) * p.D;
         if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, false, min(4, p.N - 4 * gl), q);
@@ -838,9 +885,118 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     rox = oxf; roy = oyf;
 }
 
-/* ------------------------------------------------------------------ launch 1: ownship kernel
- * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185),
- * one thread per env. */
+/* ------------------------------------------------------------------ ownship phase
+ * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185), one thread per env.
+ * The state lives in OwnRegs: the single-step kernel loads it, updates it and stores it back; the looped kernel
+ * (uam_sweep_many_kernel) keeps it in registers across the steps of a launch. */
+struct OwnRegs {
+    float ox, oy;
+    double hd, sp, gx, gy, vx, vy;
+};
+/* inputs of one step for one env */
+struct OwnIn {
+    uint32_t w0, w1;     /* action words (two 32-bit words whatever the encoding) */
+    double zh, zs;       /* ownship noise */
+};
+
+__device__ __forceinline__ void own_load(const UamParams& p, const int e, OwnRegs& r)
+{
+    r.ox = p.s.own_x[e]; r.oy = p.s.own_y[e];
+    r.hd = p.s.own_h[e]; r.sp = p.s.own_s[e];
+    r.gx = p.s.goal_x[e]; r.gy = p.s.goal_y[e];
+    r.vx = 0.0; r.vy = 0.0;
+}
+
+/* reload after another wave of the block reset this env (rare): bypass the vector L1, the values were just written */
+__device__ __forceinline__ void own_reload(const UamParams& p, const int e, OwnRegs& r)
+{
+    r.ox = __hip_atomic_load(p.s.own_x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.oy = __hip_atomic_load(p.s.own_y + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.hd = __hip_atomic_load(p.s.own_h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.sp = __hip_atomic_load(p.s.own_s + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.gx = __hip_atomic_load(p.s.goal_x + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.gy = __hip_atomic_load(p.s.goal_y + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.vx = __hip_atomic_load(p.s.own_vx + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.vy = __hip_atomic_load(p.s.own_vy + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void own_store(const UamParams& p, const int e, const OwnRegs& r)
+{
+    p.s.own_x[e] = r.ox; p.s.own_y[e] = r.oy;
+    p.s.own_h[e] = r.hd; p.s.own_s[e] = r.sp;
+    p.s.own_vx[e] = r.vx; p.s.own_vy[e] = r.vy;
+}
+
+/* action + noise of step k (k = step within the launch).  Branch-free action fetch: two 32-bit words whatever the
+ * encoding (the second aliases the first unless the action is a pair), decoded after all loads are in flight */
+template <int RNG>
+__device__ __forceinline__ void own_fetch_inputs(const UamParams& p, const int e, const int k, OwnIn& r)
+{
+    const bool is_pair = p.action_mode == UAM_ACT_PAIR;
+    const uint32_t* __restrict__ aw = (const uint32_t*)p.actions;
+    const size_t i0 = (is_pair ? 2 * (size_t)e : (size_t)e) + (size_t)k * (size_t)p.act_step_words;
+    r.w0 = aw[i0]; r.w1 = aw[is_pair ? i0 + 1 : i0];
+    if constexpr (RNG == UAM_RNG_PHILOX) {
+        const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
+        r.zh = z.x; r.zs = z.y;
+    }
+}
+
+/* the update itself: registers in, registers + the env's 48-byte LDS record out */
+template <bool KC>
+__device__ __forceinline__ void own_update(const UamParams& p, const UamCold& c, OwnRegs& r, const OwnIn& in, float4* sh)
+{
+    const int ai0 = (int)in.w0, ai1 = (int)in.w1;
+    const float af = __uint_as_float(in.w0);
+    double a0, a1;
+    bool has_speed = true;
+    if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
+    else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
+    else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
+    else { a0 = (double)af; a1 = 1.0; has_speed = false; }
+    double hd = r.hd, sp = r.sp;
+    hd += c.d_heading * (a0 - 1.0);
+    hd += 0.0 + c.heading_sigma * in.zh;
+    if (has_speed) sp += c.d_speed * (a1 - 1.0);
+    sp = fmax(c.min_speed, fmin(sp, c.max_speed));
+    sp += 0.0 + c.speed_sigma * in.zs;
+    double sn, cs;
+    sincos_sel<KC>(hd, &sn, &cs);
+    const double vx = sp * cs, vy = sp * sn;
+    const float ox = (float)((double)r.ox + vx);      /* float32 position += float64 velocity */
+    const float oy = (float)((double)r.oy + vy);
+    const double gx = r.gx, gy = r.gy;
+    /* dist(drone, goal): float32 - float64 -> float64 with the BLAS ddot FMA form */
+    const double dx = (double)ox - gx, dy = (double)oy - gy;
+    const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
+    const bool hit = dg < c.goal_r;
+    /* SingleAircraftDiscrete9HEREnv.py:217-221: leaving the map ends the episode (checked before the goal) */
+    const bool wall = p.wall_term && !(ox >= 0.f && oy >= 0.f && ox <= p.W32 && oy <= p.H32);
+    const float rew = wall ? (float)c.wall_pen
+                           : hit ? (float)c.goal_rew : (p.sparse_reward ? (float)c.step_pen : (float)(-dg / c.dense_div));
+    float t[8];
+    if (p.obs_mode == UAM_OBS_NORM4 || p.obs_mode == UAM_OBS_KNN5) {
+        t[0] = ox * p.inv_W32;
+        t[1] = oy * p.inv_H32;
+        t[2] = (float)((vx + c.max_speed) * c.inv_2vmax);
+        t[3] = (float)((vy + c.max_speed) * c.inv_2vmax);
+        t[4] = (float)((sp - c.min_speed) * c.inv_vrange);
+        t[5] = (float)(hd * (1.0 / UAM_TWO_PI));
+        t[6] = (float)(gx * c.inv_W);
+        t[7] = (float)(gy * c.inv_H);
+    } else {
+        t[0] = ox; t[1] = oy; t[2] = (float)vx; t[3] = (float)vy;
+        t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
+    }
+    r.ox = ox; r.oy = oy; r.hd = hd; r.sp = sp; r.vx = vx; r.vy = vy;
+    sh[0] = make_float4(ox, oy, rew, __uint_as_float(wall ? 2u : (hit ? 1u : 0u)));   /* tail code: 0 none, 1 goal, 2 wall */
+    sh[1] = make_float4(t[0], t[1], t[2], t[3]);
+    sh[2] = make_float4(t[4], t[5], t[6], t[7]);
+}
+
+/* single-step form (uam_sweep_kernel): load, update, store in one function — the same arithmetic as own_update,
+ * written out so that this kernel's register allocation (63 VGPRs, 8 waves/SIMD) does not depend on the looped
+ * kernel's needs; tests/test_gpu_rollout.py and the step_many tests hold the two forms bit-identical. */
 template <int RNG, bool KC = false>
 __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh, const int k = 0)
 {
@@ -931,9 +1087,24 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
 /* one step of the sweep for this block.  k = step within the launch (0 for uam_sweep_kernel; the loop index of
  * uam_sweep_many_kernel): the Philox step counter, the action / noise / reward / done / info rows advance with it;
  * obs_k = where this step emits its observation (nullptr: it does not). */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false>
-__device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k)
+/* PERSIST (uam_sweep_many_kernel): the lane's quad `q`, the ownship registers `own` (threads tid < E) and the
+ * accumulated `vel_dirty_acc` live in registers across the steps of the launch — nothing of the env state is
+ * loaded or stored here except by the rare paths (reset: own state + counters through HBM, signalled to the
+ * ownship thread through the LDS record); the caller loads before the first step and stores after the last. */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false>
+__device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k,
+                                           Quad<POS64, SH>& q_persist, bool& vel_dirty_acc, int32_t& ncf_persist,
+                                           float4* const rec_persist = nullptr, float* const stage_persist = nullptr
+#if UAM_STAMP
+                                           , unsigned long long* stamp_acc = nullptr
+#endif
+                                           )
 {
+#if UAM_STAMP
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+    Quad<POS64, SH> q_local;
+    Quad<POS64, SH>& q = PERSIST ? q_persist : q_local;
     typedef typename PosT<POS64>::type P;
     constexpr bool RI = (MODE & UAM_MODE_RI) != 0, SHAPED = (MODE & UAM_MODE_SHAPED) != 0, KNN = (MODE & UAM_MODE_KNN) != 0;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
@@ -947,9 +1118,12 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
-    Quad<POS64, SH> q;
-    float4* lds_share = (float4*)lds_raw;            /* [E][3] float4, then the obs staging */
-    {
+    /* [E][3] float4 of ownship records, then the obs staging; the looped kernel passes its own (it alternates two
+     * record sets and its ownship wave has already filled this step's, behind a block barrier) */
+    float4* lds_share = PERSIST ? rec_persist : (float4*)lds_raw;
+    if constexpr (PERSIST) {
+        if (env_first >= p.B) return;
+    } else {
         /* threads that run the ownship phase fetch their quad AFTER it, so the fp64 phase and the
          * quad never share the register file (keeps the kernel at 64 VGPRs = 8 waves/SIMD); every
          * other thread has its loads in flight while it waits at the barrier */
@@ -968,6 +1142,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     const float4* shp = (const float4*)(lds_share + 3 * (env_ok ? g : wave_first_g));
     const float4 s0 = shp[0];              /* same address for the whole lane group: one broadcast load */
     const float ox = s0.x, oy = s0.y;
+    UAM_STAMP_AT(0);
 
     P nx[4], ny[4];
     uint32_t confm = 0, oobm = 0, validm = 0;
@@ -998,6 +1173,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         oobm |= ((valid && oob) ? 1u : 0u) << j;
         first_nmac = (valid && nm && first_nmac == 0xFFFFu) ? idx : first_nmac;
     }
+    UAM_STAMP_AT(1);
     /* first NMAC index of the env: everything after it is untouched this step (:167-168) */
     const uint32_t kmin = grp_min(first_nmac, L);
     uint32_t packed = 0, resp = 0;
@@ -1006,36 +1182,50 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     double near_d = 9999.0;
     float near_d2 = 9999.0f * 9999.0f;
     uint32_t near_tag = 0;     /* (index + 1) << 1 | value-is-float64, of the intruder that set near_d */
+    /* committed slots of this lane: valid and not after the first NMAC.  Everything below is mask arithmetic and
+     * selects — no per-slot branches (twelve small divergent branches cost ~0.4 us of a 2.9 us looped step) */
+    const int rel = (int)kmin - (int)(4u * gl);                       /* kmin = 0xFFFF: all four */
+    const uint32_t cm = validm & (rel < 0 ? 0u : (rel >= 3 ? 0xFu : ((2u << rel) - 1u)));
+    if constexpr (SHAPED) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t idx = 4u * gl + j;
-        if (((validm >> j) & 1u) && idx <= kmin) {
-            if constexpr (SHAPED && !POS64) {
-                const float dx = ox - (float)nx[j], dy = oy - (float)ny[j];
-                near_d2 = fminf(near_d2, dx * dx + dy * dy);
-                near_tag = 2u;
-            }
-            if constexpr (SHAPED && POS64) {
-                const bool prom = (q.flags >> (4 + j)) & 1u;
-                double d;
-                if (prom) {
-                    const double dx = (double)ox - (double)nx[j], dy = (double)oy - (double)ny[j];
-                    d = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
-                } else {
+        for (int j = 0; j < 4; j++) {
+            const uint32_t idx = 4u * gl + j;
+            if ((cm >> j) & 1u) {
+                if constexpr (!POS64) {
                     const float dx = ox - (float)nx[j], dy = oy - (float)ny[j];
-                    d = (double)__builtin_sqrtf(dx * dx + dy * dy);
+                    near_d2 = fminf(near_d2, dx * dx + dy * dy);
+                    near_tag = 2u;
                 }
-                if (!(near_d < d)) { near_d = d; near_tag = ((idx + 1u) << 1) | (prom ? 1u : 0u); }   /* min(d, nearest): ties keep d */
+                if constexpr (POS64) {
+                    const bool prom = (q.flags >> (4 + j)) & 1u;
+                    double d;
+                    if (prom) {
+                        const double dx = (double)ox - (double)nx[j], dy = (double)oy - (double)ny[j];
+                        d = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
+                    } else {
+                        const float dx = ox - (float)nx[j], dy = oy - (float)ny[j];
+                        d = (double)__builtin_sqrtf(dx * dx + dy * dy);
+                    }
+                    if (!(near_d < d)) { near_d = d; near_tag = ((idx + 1u) << 1) | (prom ? 1u : 0u); }   /* min(d, nearest): ties keep d */
+                }
             }
-            if ((confm >> j) & 1u) {
-                packed += 0x10000u + (((q.flags >> j) & 1u) ? 0u : 1u);   /* first-time flag -> no_conflict += 1 */
-                q.flags |= 1u << j;
-            }
-            q.x[j] = nx[j]; q.y[j] = ny[j];
-            if ((oobm >> j) & 1u) resp |= 1u << j;             /* slot replaced by reset_intruder(), :151-152 */
+        }
+    }
+    {
+        const uint32_t newc = cm & confm;                             /* in conflict this step (:157-161) */
+        const uint32_t first = newc & ~q.flags & 0xFu;                /* first-time flag -> no_conflict += 1 */
+        packed = ((uint32_t)__popc(newc) << 16) + (uint32_t)__popc(first);
+        q.flags |= newc;
+        resp = cm & oobm;                                             /* slot replaced by reset_intruder(), :151-152 */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool c = (cm >> j) & 1u;
+            q.x[j] = c ? nx[j] : q.x[j];
+            q.y[j] = c ? ny[j] : q.y[j];
         }
     }
     packed = grp_add(packed, L);
+    UAM_STAMP_AT(2);
     if (UAM_ABLATE & 4) resp = 0;
     const bool nmac_any = kmin != 0xFFFFu;
     const bool conf_any = (packed >> 16) != 0;
@@ -1078,6 +1268,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         }
     }
 
+    UAM_STAMP_AT(3);
     /* ---- reward / done / info, :167-185 */
     const uint32_t tail_code = __float_as_uint(s0.w);
     bool done;
@@ -1111,6 +1302,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         if (env_ok && gl == 0) p.s.nearest[env] = (float)gmin;
     }
 
+    UAM_STAMP_AT(4);
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
@@ -1165,13 +1357,20 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         }
     }
 
+    UAM_STAMP_AT(5);
     /* ---- per-env outputs (one lane per env) */
     if (env_ok && gl == 0) {
         const size_t orow = (size_t)k * (size_t)p.B + (size_t)env;
         p.reward[orow] = reward;
         p.done[orow] = done ? 1 : 0;
         if (p.info) p.info[orow] = (uint8_t)info;
-        if (!(done && p.auto_reset) && new_conf) p.s.no_conflict[env] += (int32_t)new_conf;
+        if constexpr (PERSIST) {
+            /* env.no_conflict of the group's env lives in lane 0's register for the launch (no load -> add -> store
+             * round trip inside the step); a reset zeroes it (:94) */
+            ncf_persist = (done && p.auto_reset) ? 0 : ncf_persist + (int32_t)new_conf;
+        } else {
+            if (!(done && p.auto_reset) && new_conf) p.s.no_conflict[env] += (int32_t)new_conf;
+        }
         if (p.track_ep) {   /* Monitor.step, baselines/bench/monitor.py:58-75 */
             const double r = p.s.ep_ret[env] + (double)reward;
             const int32_t l = p.s.ep_len[env] + 1;
@@ -1181,6 +1380,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         }
     }
 
+    UAM_STAMP_AT(6);
     /* ownship/goal part of the obs: lanes 0 and 1 of the group carry one float4 each */
     const int second = L > 1 ? 1 : 0;
     float tail[8];
@@ -1198,25 +1398,48 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
         reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true;
+        if constexpr (PERSIST) {
+            /* tell the env's ownship thread (in the block's ownship wave) to pick the new episode's state up:
+             * every lane of the group has read its record by now (s0 above, the tail just before); the new state
+             * must have reached L2 before the mark is seen */
+            if (gl == 0) { __threadfence(); ((uint32_t*)(lds_share + 3 * g))[3] = 0xFFFFFFFFu; }
+        }
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
 
+    UAM_STAMP_AT(7);
     /* ---- commit state + obs pack */
-    if (quad_ok) {
+    if constexpr (PERSIST) {
+        vel_dirty_acc = vel_dirty_acc || vel_dirty;
+    } else if (quad_ok) {
         if (!(UAM_ABLATE & 16)) quad_store_pos<POS64, SH>(p, base, q);
         if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (obs_k && !(UAM_ABLATE & 2)) {
-        float* stage = (float*)(lds_raw + (size_t)p.E * 48) + (size_t)wave_first_g * p.D;
+        float* stage = (PERSIST ? stage_persist : (float*)(lds_raw + (size_t)p.E * 48)) + (size_t)wave_first_g * p.D;
         if constexpr (KNN) {
             float* row = p.obs_vec ? stage + (size_t)(g - wave_first_g) * p.D : obs_k + (size_t)(env_ok ? env : 0) * p.D;
             knn_row<POS64, SH>(p, row, gl, L, env_ok, quad_ok, q, kx, ky, tail);
-            if (p.obs_vec) obs_copy_out(p, obs_k, stage, env_first, tid & 63);
+            if (p.obs_vec) obs_copy_out<PERSIST>(p, obs_k, stage, env_first, tid & 63);
         } else {
-            obs_pack_wave<POS64, SH>(p, obs_k, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+            bool direct = false;
+            if constexpr (PERSIST) direct = p.obs_direct != 0 && p.obs_vec != 0;
+            if (direct) {
+                /* latency regime of the looped kernel (one or two waves per SIMD): every lane stores its 64 bytes
+                 * of the row straight from registers — no LDS round trip on the step's critical path; the
+                 * partial-line stores this makes only cost when the launch is bandwidth-bound, which it is not */
+                if (env_ok) {
+                    float* row = obs_k + (size_t)env * p.D;
+                    if (quad_ok) quad_obs<POS64, SH>(p, row + (size_t)(4 * gl) * p.obs_w, true, min(4, p.N - 4 * gl), q);
+                    store_tail(p, row + (size_t)p.N * p.obs_w, true, gl, tail);
+                }
+            } else {
+                obs_pack_wave<POS64, SH, PERSIST>(p, obs_k, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
+            }
         }
     }
+    UAM_STAMP_AT(8);
 }
 
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
@@ -1226,20 +1449,105 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
     /* exact-promotion Philox instances: the fp64 spawn sits inside the respawn loop, and the SGPR-pinned sincos
      * flavour keeps its literals out of the VGPRs held across that loop (131 -> 91 VGPRs, -6 % step time).  The
      * RandIntruder and MT19937 instances measure slower with it (+3...16 %) and keep the plain flavour. */
-    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX)>(p, lds_raw, 0, p.obs);
+    Quad<POS64, SH> q;
+    bool vd = false;
+    int32_t ncf = 0;
+    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX), false>(p, lds_raw, 0, p.obs, q, vd, ncf);
 }
 
-/* K consecutive steps in ONE launch (uam_step_many, Philox): envs never interact and a block only ever touches
- * its own E envs, so the block simply runs its envs' steps back to back — state through HBM/L2 as usual, one
- * block barrier between steps (a reset writes the ownship from another wave than the one that reads it next).
- * Removes K - 1 launches: small batches (4096 x 8, 8192 x 64) are launch-latency bound, not HBM bound.
- * The observation is emitted by the last step only. */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
-__global__ void UAM_STEP_BOUNDS uam_sweep_many_kernel(const UamParams p)
+/* K consecutive steps in ONE launch (uam_step_many / uam_rollout, float32 + Philox): envs never interact and a
+ * block only ever touches its own E envs, so the block simply runs its envs' steps back to back.
+ *  - The env state is REGISTER-RESIDENT for the whole launch: each lane loads its quad once, K steps run on
+ *    registers, and the state is written back once at the end.  Per step the launch moves only the step's outputs
+ *    (observation, reward, done, info) and inputs (action, noise): no state round trip through L2/HBM.
+ *  - The block has one extra wave, the OWNSHIP WAVE (threads T .. T+63, lane i = env i of the block), which holds
+ *    the ownship/goal registers and runs ONE STEP AHEAD of the sweeping waves: while they sweep step k from record
+ *    set k&1 it computes the ownship phase of step k+1 (fp64 trig, goal distance, reward tail, obs tail) into
+ *    record set (k+1)&1 and prefetches the inputs of step k+2 — the fp64 chain is off the sweepers' critical path.
+ *    That is speculative in one respect only: an env that terminates in step k starts a new episode, so its step
+ *    k+1 must start from the reset state.  The sweepers mark such envs in the record of step k; after barrier A
+ *    the ownship wave re-reads the marked envs' new state and recomputes their step k+1 (rare: ~0.6 % of env-steps
+ *    under a goal-seeking policy) before barrier B releases the sweepers.
+ * Removes K - 1 launches and the dependent loads at the head of every step: small batches (4096 x 8, 8192 x 32 per
+ * GPU of a sharded 65536 batch, 8192 x 64) are launch- and latency-bound, not HBM-bound. */
+/* OWNW = the block has the ownship wave (latency regime: one or two waves per SIMD, the fp64 chain is hidden).
+ * !OWNW = a shard that needs every wave slot of the chip for its sweeping waves (32768 x 32: 16 waves per CU) has
+ * no room for ownship waves: threads tid < E of the sweeping waves run the ownship phase at the head of each step,
+ * as in the single-step kernel, with their registers persistent too. */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool OWNW>
+__device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned char* lds_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int K = p.many_K;
+    const int T = (int)blockDim.x - (OWNW ? 64 : 0);  /* sweeping threads; with OWNW the last wave is the ownship wave */
+    const int tid = threadIdx.x;
+    const bool is_own_wave = OWNW && tid >= T;
+    float4* const rec0 = (float4*)lds_raw;            /* two sets of [E][3] float4 records, then the obs staging */
+    float4* const rec1 = rec0 + 3 * p.E;
+    float* const stage = (float*)(lds_raw + (size_t)p.E * 96);
     const size_t slot_elems = (size_t)p.B * (size_t)p.D;
+
+    if (is_own_wave) {
+        /* ---------------- ownship wave */
+        const UamParams& pk = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int lane = tid - T;
+        const int e = blockIdx.x * p.E + lane;
+        const bool owns = lane < p.E && e < p.B;
+        OwnRegs own;
+        OwnIn cur, nxt;
+        if (owns) {
+            own_load(p, e, own);
+            own_fetch_inputs<RNG>(p, e, 0, cur);
+            own_update<true>(pk, *pk.c, own, cur, rec0 + 3 * lane);           /* step 0 */
+            if (K > 1) own_fetch_inputs<RNG>(p, e, 1, cur);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            float4* const rec_k = (k & 1) ? rec1 : rec0;
+            float4* const rec_n = (k & 1) ? rec0 : rec1;
+            if (owns && k + 1 < K) {
+                own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
+                if (k + 2 < K) own_fetch_inputs<RNG>(p, e, k + 2, nxt);
+            }
+            __syncthreads();                                                   /* A: sweep k done */
+            if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
+                own_reload(p, e, own);                                         /* env was reset in step k */
+                if (k + 1 < K) own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
+            }
+            cur = nxt;
+            __syncthreads();                                                   /* B: record k+1 final */
+        }
+        if (owns) own_store(p, e, own);
+        return;
+    }
+
+    /* ---------------- sweeping waves */
+    const int g = tid >> p.lshift, gl = tid & (p.L - 1);
+    const int env = blockIdx.x * p.E + g;
+    const bool quad_ok = env < p.B && gl < p.Q;
+    const size_t base = (size_t)env * p.Np + 4u * gl;
+    Quad<POS64, SH> q;
+    bool vel_dirty = false;
+    /* !OWNW: this thread is also the ownship thread of env blockIdx.x * E + tid */
+    const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int own_e = blockIdx.x * p.E + tid;
+    const bool owns = !OWNW && tid < p.E && own_e < p.B;
+    OwnRegs own;
+    OwnIn oin;
+    if (owns) {
+        own_load(p, own_e, own);
+        own_fetch_inputs<RNG>(p, own_e, 0, oin);
+    }
+#if UAM_STAMP
+    unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    quad_load<POS64, SH>(p, base, quad_ok, q);
+    int32_t ncf = (env < p.B && gl == 0) ? p.s.no_conflict[env] : 0;
+    /* drain the state loads HERE: vmcnt counts loads and stores together and in order, so a wait for these loads
+     * placed inside the loop (where the compiler would put it, at the first use of the quad) would make every later
+     * step wait for the previous step's observation stores to be acknowledged (measured: 1.6 of 2.9 us per step) */
+    __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */
+    __syncthreads();
     int slot = 0;
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
@@ -1248,9 +1556,58 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_many_kernel(const UamParams p)
             if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
             else if (k == K - 1) obs_k = p.obs;
         }
-        sweep_step<POS64, RNG, MODE, SH, ROS, true>(p, lds_raw, k, obs_k);
-        __syncthreads();
+        if constexpr (!OWNW) {
+            if (owns) {
+                own_update<true>(pko, *pko.c, own, oin, rec0 + 3 * tid);
+                if (k + 1 < K) own_fetch_inputs<RNG>(pko, own_e, k + 1, oin);   /* in flight while this step sweeps */
+            }
+            __syncthreads();
+        }
+        float4* const rec_k = (OWNW && (k & 1)) ? rec1 : rec0;
+#if UAM_STAMP
+        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, obs_k, q, vel_dirty, ncf, rec_k, stage, stamp_acc);
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        __syncthreads();                                                       /* A */
+        if constexpr (OWNW) __syncthreads();                                   /* B */
+        stamp_acc[9] += __builtin_amdgcn_s_memtime() - tb;
+#else
+        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, obs_k, q, vel_dirty, ncf, rec_k, stage);
+        __syncthreads();                                                       /* A */
+        if constexpr (OWNW) __syncthreads();                                   /* B */
+#endif
+        if constexpr (!OWNW) {
+            if (owns && ((const uint32_t*)(rec0 + 3 * tid))[3] == 0xFFFFFFFFu) own_reload(p, own_e, own);   /* env was reset */
+        }
     }
+    if (owns) own_store(p, own_e, own);
+#if UAM_STAMP
+    if (p.actions_out && (tid & 63) == 0) {
+        unsigned long long* dst = (unsigned long long*)p.actions_out + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * UAM_NSTAMP;
+        for (int i = 0; i < UAM_NSTAMP; i++) dst[i] = stamp_acc[i];
+    }
+#endif
+    if (quad_ok) {
+        quad_store_pos<POS64, SH>(p, base, q);
+        if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
+        p.s.qf[base >> 2] = (uint8_t)q.flags;
+    }
+    if (env < p.B && gl == 0) p.s.no_conflict[env] = ncf;
+}
+
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+__global__ void UAM_MANY_BOUNDS uam_sweep_many_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    sweep_many_body<POS64, RNG, MODE, SH, ROS, true>(p, lds_raw);
+}
+
+/* the flavour without ownship wave, held at 4 waves/SIMD (128 VGPRs, a few spills) so that 16 sweeping waves per CU
+ * are resident: 1024 blocks of 256 threads = 32768 envs x 32 intruders in one round */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) uam_sweep_many4_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    sweep_many_body<POS64, RNG, MODE, SH, ROS, false>(p, lds_raw);
 }
 
 /* reset kernel: uam_reset (all envs or mask).  LDS: E*D floats of obs staging (aligned obs only). */

@@ -39,6 +39,10 @@ struct uam_env {
     int device;
     int Np, Q, L, lshift, T, E, D, hold_sh;
     int num_cus;                /* compute units of the device (hipDeviceProp_t::multiProcessorCount) */
+    int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
+    int many4_resident_blocks;  /* the same for the flavour without ownship wave */
+    int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
+    int Tm, Em;                 /* looped kernel: sweeping threads per block (+ 64 for its ownship wave), envs per block <= 64 */
     uint32_t step_index;        /* uam_step calls so far */
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
     double2* noise_many;        /* [noise_many_cap][B] noise of one uam_step_many launch (grown on demand) */
@@ -57,6 +61,12 @@ struct uam_env {
     int64_t timed_launches;
     uint32_t policy_calls;
 };
+
+typedef void (*UamSweepFn)(const UamParams);
+static UamSweepFn many_fn(const uam_env* e);
+static bool many_instance_exists(const uam_env* e);
+static UamSweepFn many4_fn(const uam_env* e);
+static inline size_t lds_many(const uam_env* e, int fl, bool staged);
 
 extern "C" const char* uam_last_error(void) { return g_err; }
 extern "C" const char* uam_version(void) { return "uamenv-hip 0.1 (gfx950, abi 1)"; }
@@ -93,7 +103,7 @@ extern "C" int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = pi / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
     c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
-    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->reserved1 = 0;
+    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->fuse_rollout = 0;
     return UAM_OK;
 }
 
@@ -122,6 +132,7 @@ static int validate(const uam_config* c)
     if (c->dynamics < 0 || c->dynamics > UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "bad dynamics %d", c->dynamics);
     if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
     if (c->precision < 0 || c->precision > UAM_POS_EXACT) return fail(UAM_EINVAL, "bad precision %d", c->precision);
+    if (c->fuse_rollout < 0 || c->fuse_rollout > UAM_FUSE_NEVER) return fail(UAM_EINVAL, "bad fuse_rollout %d", c->fuse_rollout);
     if (!(c->window_width > 0) || !(c->window_height > 0)) return fail(UAM_EINVAL, "window must be positive");
     if (!(c->max_speed > c->min_speed)) return fail(UAM_EINVAL, "max_speed must exceed min_speed");
     if (!(c->initial_min_dist >= 0) || c->initial_min_dist * 2 >= fmin(c->window_width, c->window_height))
@@ -288,6 +299,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (T < 64) T = 64;
     e->T = T;
     e->E = T / L;
+    e->Tm = T < 64 * L ? T : 64 * L;      /* the ownship wave has one lane per env of the block */
+    e->Em = e->Tm / L;
     e->D = uam_obs_dim(cfg);
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
     /* Philox configurations run the ownship phase inside the sweep launch (one launch per step); the
@@ -344,6 +357,20 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
         if (!rc) rc = dev_alloc(e, &e->s.mt_gen, (size_t)B);
         if (!rc) rc = dev_alloc(e, &e->s.mt_has_gauss, (size_t)B);
         if (!rc) rc = dev_alloc(e, &e->s.mt_gauss, (size_t)B);
+    }
+    e->many_resident_blocks = 0;
+    e->many4_resident_blocks = 0;
+    e->many_obs_direct = 0;
+    if (!rc && many_instance_exists(e)) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many_fn(e), e->Tm + 64, lds_many(e, 1, true)) != hipSuccess) per_cu = 0;
+        e->many_resident_blocks = per_cu * e->num_cus;
+        if (many4_fn(e)) {
+            per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many4_fn(e), e->T, lds_many(e, 2, true)) != hipSuccess) per_cu = 0;
+            e->many4_resident_blocks = per_cu * e->num_cus;
+        }
+        if (const char* od = getenv("UAMENV_OBS_DIRECT")) e->many_obs_direct = atoi(od);   /* development override */
     }
     if (!rc && hipEventCreate(&e->ev0) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
     if (!rc && hipEventCreate(&e->ev1) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
@@ -437,37 +464,101 @@ static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
 }
 
 /* K steps in one launch (float32 / Philox instances only; everything else loops over single steps) */
+
 template <int MODE, bool SH>
-static void launch_many_ros(const uam_env* e, const UamParams& p, hipStream_t st)
+static UamSweepFn many_fn_ros(const uam_env* e)
 {
-    dim3 grid(grid_of(e)), block(e->T);
-    const size_t lds = lds_stage(e, p) + (size_t)e->E * 48;
-    if (e->cfg.random_own_start)
-        hipLaunchKernelGGL((uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, true>), grid, block, lds, st, p);
-    else
-        hipLaunchKernelGGL((uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, false>), grid, block, lds, st, p);
+    if (e->cfg.random_own_start) return uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, true>;
+    return uam_sweep_many_kernel<false, UAM_RNG_PHILOX, MODE, SH, false>;
 }
 
-static void launch_many(const uam_env* e, const UamParams& p, hipStream_t st)
+static UamSweepFn many_fn(const uam_env* e)
 {
     const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;
-    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_many_ros<UAM_MODE_RI, true>(e, p, st);
-    else if (knn && e->cfg.shaped_reward) launch_many_ros<UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e, p, st);
-    else if (knn) launch_many_ros<UAM_MODE_KNN, false>(e, p, st);
-    else if (e->cfg.shaped_reward && !e->hold_sh) launch_many_ros<UAM_MODE_SHAPED, false>(e, p, st);
-    else if (e->hold_sh) launch_many_ros<0, true>(e, p, st);
-    else launch_many_ros<0, false>(e, p, st);
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) return many_fn_ros<UAM_MODE_RI, true>(e);
+    if (knn && e->cfg.shaped_reward) return many_fn_ros<UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e);
+    if (knn) return many_fn_ros<UAM_MODE_KNN, false>(e);
+    if (e->cfg.shaped_reward && !e->hold_sh) return many_fn_ros<UAM_MODE_SHAPED, false>(e);
+    if (e->hold_sh) return many_fn_ros<0, true>(e);
+    return many_fn_ros<0, false>(e);
 }
 
-static bool many_supported(const uam_env* e)
+static bool many_instance_exists(const uam_env* e)
 {
-    /* the looped kernel holds 115-166 VGPRs (3 waves/SIMD at worst = 3 of these 4-wave blocks per CU): it only pays
-     * while the whole grid is resident in one round — which is exactly the launch-bound small-batch regime */
-    const int resident_blocks = e->num_cus * 3 * 256 / e->T;
-    return e->cfg.rng_mode == UAM_RNG_PHILOX && e->cfg.precision == UAM_POS_F32 &&
-           !(e->cfg.shaped_reward && e->hold_sh) && !e->ktiming &&
-           grid_of(e) <= resident_blocks;
+    return e->cfg.rng_mode == UAM_RNG_PHILOX && e->cfg.precision == UAM_POS_F32 && !(e->cfg.shaped_reward && e->hold_sh);
 }
+
+/* the flavour without ownship wave exists for the plain step only (discrete-9 / continuous, normalised or raw obs) */
+static UamSweepFn many4_fn(const uam_env* e)
+{
+    if (!many_instance_exists(e) || e->cfg.dynamics == UAM_DYN_RANDINTRUDER || e->cfg.obs_mode == UAM_OBS_KNN5 ||
+        e->cfg.shaped_reward || e->hold_sh)
+        return nullptr;
+    if (e->cfg.random_own_start) return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, true>;
+    return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, false>;
+}
+
+/* launch geometry of the looped kernel by flavour (1: ownship wave, 2: none) */
+static inline int many_E(const uam_env* e, int fl) { return fl == 2 ? e->E : e->Em; }
+static inline int many_threads(const uam_env* e, int fl) { return fl == 2 ? e->T : e->Tm + 64; }
+static inline int grid_many(const uam_env* e, int fl) { return (e->cfg.num_envs + many_E(e, fl) - 1) / many_E(e, fl); }
+static inline size_t lds_many(const uam_env* e, int fl, bool staged)
+{
+    return (staged ? (size_t)many_E(e, fl) * e->D * 4 : 0) + (size_t)many_E(e, fl) * 96;
+}
+
+/* which flavour runs a chunk on this handle (0: none, K single-step launches are queued).  The looped kernel keeps the
+ * env state in registers for the whole launch, so it is used while its whole grid is resident in ONE round at the
+ * occupancy the runtime reports: first choice the ownship-wave flavour, else the one that leaves every wave slot to
+ * the sweeping waves */
+static int many_flavour(const uam_env* e)
+{
+    if (!many_instance_exists(e) || e->ktiming) return 0;
+    if (const char* f = getenv("UAMENV_MANY")) {       /* development override: off / force / force4 */
+        if (!strcmp(f, "off")) return 0;
+        if (!strcmp(f, "force")) return 1;
+        if (!strcmp(f, "force4")) return many4_fn(e) ? 2 : 0;
+    }
+    if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return 0;
+    if (grid_many(e, 1) <= e->many_resident_blocks) return 1;
+    if (e->many4_resident_blocks > 0 && grid_many(e, 2) <= e->many4_resident_blocks) return 2;
+    /* several rounds of blocks: register-resident state still saves the per-step state traffic (measured 1.25-1.4x
+     * over single-step launches at 65536 ... 1 M envs x 32), but the launch is no longer a latency-regime one */
+    if (e->cfg.fuse_rollout == UAM_FUSE_ALWAYS) return many4_fn(e) ? 2 : 1;
+    return 0;
+}
+
+static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
+{
+    const int fl = many_flavour(e);
+    p.E = many_E(e, fl);
+    p.obs_direct = e->many_obs_direct;
+    dim3 grid(grid_many(e, fl)), block(many_threads(e, fl));
+    const size_t lds = lds_many(e, fl, p.obs_vec != 0);
+#if UAM_STAMP
+    if (fl == 1) {   /* development build: per-phase s_memtime sums of every sweeping wave, averaged and printed per launch */
+        const int nw = grid_many(e, 1) * (e->Tm / 64);
+        static unsigned long long* dbuf = nullptr; static int dcap = 0;
+        if (dcap < nw) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void**)&dbuf, (size_t)nw * UAM_NSTAMP * 8); dcap = nw; }
+        (void)hipMemsetAsync(dbuf, 0, (size_t)nw * UAM_NSTAMP * 8, st);
+        p.actions_out = dbuf;
+        hipLaunchKernelGGL(many_fn(e), grid, block, lds, st, p);
+        std::vector<unsigned long long> h((size_t)nw * UAM_NSTAMP);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[UAM_NSTAMP] = {0};
+        for (int w = 0; w < nw; w++) for (int i = 0; i < UAM_NSTAMP; i++) sum[i] += (double)h[(size_t)w * UAM_NSTAMP + i];
+        fprintf(stderr, "[stamp] K=%d waves=%d ticks/step:", p.many_K, nw);
+        double tot = 0;
+        for (int i = 0; i < UAM_NSTAMP; i++) { fprintf(stderr, " %.0f", sum[i] / nw / p.many_K); tot += sum[i] / nw / p.many_K; }
+        fprintf(stderr, "  total %.0f\n", tot);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(fl == 2 ? many4_fn(e) : many_fn(e), grid, block, lds, st, p);
+}
+
+static bool many_supported(const uam_env* e) { return many_flavour(e) != 0; }
 
 /* one env.step() = one launch: ownship phase (thread per env) and intruder sweep (lane group per env) */
 static const int KTIMING_MAX = 256;
@@ -789,6 +880,20 @@ extern "C" int64_t uam_step_bytes(const uam_env* e)
     const int64_t per_int = 4 * posb + 8 + 4 * obs_w + (e->hold_sh ? 16 : 0);
     const int64_t per_env = 150 + (knn ? 4 * (5 * (int64_t)e->cfg.knn - 4) : 0);
     return (int64_t)e->cfg.num_envs * (per_int * e->cfg.num_intruders + per_env);
+}
+
+extern "C" int64_t uam_rollout_bytes(const uam_env* e, int32_t K)
+{
+    if (!e || K < 1) return 0;
+    if (!(K > 1 && many_supported(e))) return (int64_t)K * uam_step_bytes(e);
+    /* looped kernel: the state crosses HBM once per launch (read x,y,vx,vy + write x,y per intruder, + held
+     * speed/heading read; per env the ownship/goal/flags/counter part of SURVEY's 150 B: 88 B), every step moves only
+     * its outputs (observation row, reward, done, info) and inputs (action, 16 B of pre-drawn noise) */
+    const int64_t N = e->cfg.num_intruders, B = e->cfg.num_envs;
+    const int64_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    const int64_t state = (24 + (e->hold_sh ? 16 : 0)) * N + 88;
+    const int64_t io = 4 * (int64_t)e->D + 6 + abytes + 16;
+    return B * (state + (int64_t)K * io);
 }
 
 extern "C" int uam_kernel_timing(uam_env* e, int32_t enable)

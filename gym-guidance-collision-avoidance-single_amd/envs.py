@@ -71,6 +71,9 @@ _RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
 _PREC = {"f32": capi.POS_F32, "exact": capi.POS_EXACT}
 
 
+_FUSE = {"auto": 0, "always": 1, "never": 2}
+
+
 def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox", precision="f32", seed=0,
                 auto_reset=True, env_id_offset=0, config=Config, **overrides):
     """Build a `uam_config` from the (possibly edited) `Config` class plus explicit field overrides."""
@@ -98,6 +101,8 @@ def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox",
     for k, v in overrides.items():
         if not hasattr(cfg, k):
             raise AttributeError("uam_config has no field %r" % k)
+        if k == "fuse_rollout" and isinstance(v, str):
+            v = _FUSE[v]
         setattr(cfg, k, v)
     return cfg
 
@@ -370,6 +375,10 @@ class BatchedSingleAircraftEnv:
     @property
     def step_bytes(self):
         return int(self._lib.uam_step_bytes(self._h))
+
+    def rollout_bytes(self, K):
+        """Algorithmic HBM bytes of one K-step rollout call as this handle runs it (looped kernel: state once)."""
+        return int(self._lib.uam_rollout_bytes(self._h, int(K)))
 
     def timing_begin(self):
         capi.check(self._lib.uam_timing_begin(self._h, self._stream()))

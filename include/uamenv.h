@@ -135,8 +135,14 @@ typedef struct uam_config {
     double goal_margin;        /* goal drawn in [m, W-m] x [m, H-m]: 100 in random_goal_pos (:349-353), 0 elsewhere */
     int32_t shaped_reward;     /* 1: the non-terminal step reward gets + (conflict_coeff * d - 0.1) when the nearest swept
                                   intruder is closer than 3 * minimum_separation (:225-232) */
-    int32_t reserved1;
+    int32_t fuse_rollout;      /* uam_step_many / uam_rollout: UAM_FUSE_AUTO (0) runs a chunk as ONE looped launch while the
+                                  whole grid is resident in one round (small batches, shards of a partitioned batch) and as
+                                  K queued single-step launches otherwise; UAM_FUSE_ALWAYS (1) uses the looped kernel
+                                  whenever the handle's modes have one (float32 + Philox), in as many rounds as the grid
+                                  needs; UAM_FUSE_NEVER (2).  Results are identical in every case. */
 } uam_config;
+
+enum { UAM_FUSE_AUTO = 0, UAM_FUSE_ALWAYS = 1, UAM_FUSE_NEVER = 2 };
 
 /* HOST-side view used by uam_get_state / uam_set_state (checkpoint, parity
  * injection).  Any pointer may be NULL = skip that field.  Per-intruder
@@ -268,6 +274,12 @@ int uam_policy(uam_env* env, int32_t kind, uint64_t policy_seed, void* actions_o
 /* Algorithmic HBM bytes moved by one uam_step over the whole batch (SURVEY §8d
  * accounting restated for the handle's modes); used for the roofline figure. */
 int64_t uam_step_bytes(const uam_env* env);
+
+/* The same for one uam_step_many / uam_rollout call of K steps as this handle would run it: K * uam_step_bytes for
+ * queued single-step launches; for the looped kernel, whose env state stays in registers for the whole launch, the
+ * state once (24 B per intruder + 88 B per env) plus K times the step's outputs and inputs (observation row, reward,
+ * done, info, action, 16 B of noise). */
+int64_t uam_rollout_bytes(const uam_env* env, int32_t K);
 
 /* Average device time in milliseconds per uam_step kernel over the launches
  * recorded between uam_timing_begin and uam_timing_end (hipEvents on `stream`). */

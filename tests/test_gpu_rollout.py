@@ -25,7 +25,8 @@ def uamenv():
     ("continuous", 8192, 32, 12, 2, True),     # BASELINE config 4's per-GPU shard at N=8: looped kernel, double buffer
     ("randintruder", 512, 64, 5, 1, True),     # one buffer overwritten every step
     ("her9", 700, 20, 9, 4, True),
-    ("discrete9", 32768, 32, 5, 3, False),     # grid larger than one resident round: K queued single-step launches
+    ("discrete9", 32768, 32, 5, 3, True),      # every wave slot taken by sweeping waves: the flavour without ownship wave
+    ("discrete9", 65536, 32, 4, 2, False),     # grid larger than one resident round: K queued single-step launches
     ("discrete9", 300, 5, 6, 6, True),         # D = 28: 16-byte aligned rows only every 4th env
 ])
 def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
