@@ -15,6 +15,9 @@ Same rules as make_golden.py: data only, reference imported unmodified under the
       Agent.py plans with on SingleAircraftMCTSEnv observations): states [C, 4N+8].  Upstream quirks recorded
       as they are: the last intruder is ignored ((len - 9) // 4) and the speed is re-derived from the ownship's
       previous vy (state[-5]) every frame.
+  g18_mcts4_move_zero_*: the 4-wide model with EVERY sigma zero (heading_sigma too): move() is then a deterministic
+      function of (state, action) — whatever the random stream — so the GPU's uam_mcts_move (Philox) can be compared
+      with the reference's next state and flags DIRECTLY, without the oracle in between.
 """
 import os
 import sys
@@ -171,7 +174,37 @@ def main4(Config, mcfg, search):
         gen_moves(nodes4, roots, "g16_mcts4_move_n8_noisy", width=4)
     finally:
         mcfg.position_sigma, mcfg.speed_sigma = keep
+    main_zero(Config, mcfg)
+
+
+def main_zero(Config, mcfg):
+    """Zero-noise move() cases of the 4-wide model: deterministic, RNG-independent."""
+    import nodes_single as nodes4
+    import SingleAircraftMCTSEnv as m_mcts
+    keep = (mcfg.position_sigma, mcfg.speed_sigma, mcfg.heading_sigma)
+    mcfg.position_sigma, mcfg.speed_sigma, mcfg.heading_sigma = 0.0, 0.0, 0.0
+    try:
+        for N, seed in ((8, 61), (20, 62)):
+            roots = collect_roots(Config, m_mcts, N, seed, 8, 31)
+            gen_moves(nodes4, roots, "g18_mcts4_move_zero_n%d" % N, width=4)
+        base = collect_roots(Config, m_mcts, 8, 64, 3, 29)
+        stress = []
+        for r in base:
+            own = r[-8:].copy()
+            hx, hy = np.cos(own[5]), np.sin(own[5])
+            a = r.copy(); a[0] = own[0] + 30 * hx; a[1] = own[1] + 30 * hy; a[2] = -hx; a[3] = -hy; stress.append(a)
+            b = r.copy(); b[-8] = 796.5; b[-7] = 400.0; b[-3] = 0.0; b[0:32:4] = np.linspace(100, 500, 8); b[1:32:4] = 100.0; stress.append(b)
+            c = r.copy(); c[-2] = own[0] + 25 * hx; c[-1] = own[1] + 25 * hy; stress.append(c)
+            d = r.copy(); d[28] = own[0] + 20 * hx; d[29] = own[1] + 20 * hy; d[30] = -hx; d[31] = -hy; stress.append(d)
+        gen_moves(nodes4, np.stack(stress), "g18_mcts4_move_zero_n8_flags", width=4)
+    finally:
+        mcfg.position_sigma, mcfg.speed_sigma, mcfg.heading_sigma = keep
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "zero":      # only the g18 fixtures
+        sys.dont_write_bytecode = True
+        _Config, _m_ri, _nodes, _search, _mcfg = load_mcts("/root/reference")
+        main_zero(_Config, _mcfg)
+    else:
+        main()

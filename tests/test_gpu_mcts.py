@@ -148,6 +148,29 @@ def test_straight4_move_matches_oracle_bit_exact(uamenv, oracle, name, over):
         assert seen.min() > 0
 
 
+@pytest.mark.parametrize("name", ["g18_mcts4_move_zero_n8", "g18_mcts4_move_zero_n20", "g18_mcts4_move_zero_n8_flags"])
+def test_straight4_zero_noise_move_matches_the_reference_directly(uamenv, name):
+    """No oracle in between: with every sigma zero SingleAircraftState.move (nodes_single.py:39-100) is a
+    deterministic function of (state, action), so uam_mcts_move — Philox stream, portable math — must reproduce what
+    the REFERENCE returned (fixture recorded by make_golden_mcts.py): flags bit-exact, next state and reward to the
+    rounding of libm-vs-portable sincos / pow (<= 1e-10 on coordinates up to 800)."""
+    fx = gu.load(name)
+    N = int(fx["meta_N"])
+    planner = uamenv.BatchedMCTS(N, seed=123, model="straight4", position_sigma=0.0, speed_sigma=0.0, heading_sigma=0.0)
+    nxt, flags, rew = planner.move(fx["states"], fx["actions"], root_id0=7, sim=3, move=1)
+    nxt, flags, rew = nxt.cpu().numpy(), flags.cpu().numpy(), rew.cpu().numpy()
+    assert np.array_equal(flags, fx["flags"]), np.argwhere(flags != fx["flags"])[:4]
+    d = np.abs(nxt - fx["next_states"])
+    assert d.max() <= 1e-10, (d.max(), np.unravel_index(d.argmax(), d.shape))
+    assert np.abs(rew - fx["rewards"]).max() <= 1e-12
+    # and it does not depend on the random stream at all
+    n2, f2, r2 = uamenv.BatchedMCTS(N, seed=9, model="straight4", position_sigma=0.0, speed_sigma=0.0,
+                                    heading_sigma=0.0).move(fx["states"], fx["actions"], root_id0=99, sim=0, move=0)
+    assert np.array_equal(n2.cpu().numpy(), nxt) and np.array_equal(f2.cpu().numpy(), flags)
+    if name.endswith("flags"):
+        assert fx["flags"].sum(0).min() > 0
+
+
 @pytest.mark.parametrize("name,sims,depth", [("g17_mcts4_search_n8", 100, 3), ("g17_mcts4_search_n20", 100, 3),
                                              ("g17_mcts4_search_n8", 200, 4)])
 def test_straight4_best_action_matches_oracle_bit_exact(uamenv, oracle, name, sims, depth):

@@ -97,9 +97,37 @@ def test_gpu_replays_reference_fixture_from_seed(uamenv, name):
     tol = 1e-5
 
     def close(a, b, what):
+        """north_star's 1e-5 abs on normalised observations; RAW observations carry positions up to 800 whose float32
+        ulp is 6.1e-5, so there the bound is ONE float32 ulp of the value (device trig / log vs glibc)."""
         d = np.abs(a.astype(np.float64) - b)
-        lim = tol * (np.maximum(1.0, np.abs(b)) if raw else 1.0)   # raw obs carry positions up to 800 (fp32 ulp 6e-5)
-        assert (d <= lim).all(), "%s: max |d| = %g" % (what, d.max())
+        lim = np.maximum(np.spacing(np.abs(b).astype(np.float32)).astype(np.float64), 1e-7) if raw else tol
+        assert (d <= lim).all(), "%s: max |d| = %g (limit %g)" % (what, d.max(), np.max(lim))
+
+    st_index = {int(t): i for i, t in enumerate(fx["st_steps"])} if "st_steps" in fx else {}
+    hold_sh = variant == "randintruder"
+
+    def check_snapshot(t, where):
+        """the fixture's SoA snapshot after step t against uam_get_state: flags and counters exact, float32 fields
+        within one float32 ulp, float64 fields to 1e-9 relative (device trig vs glibc, never accumulated bits)"""
+        if t not in st_index:
+            return
+        want = gu.prefixed_state(fx, "st_", st_index[t])
+        got = env.get_state([k for k in want if k in ("int_x", "int_y", "int_vx", "int_vy", "int_conflict", "int_promoted",
+                                                      "own_x", "own_y", "own_heading", "own_speed", "own_vx", "own_vy",
+                                                      "goal_x", "goal_y", "no_conflict") or (hold_sh and k in ("int_speed", "int_heading"))])
+        for k, g in got.items():
+            if k == "step_index":
+                continue
+            w = want[k]
+            if g.dtype.kind in "ui":
+                assert np.array_equal(g, w.astype(g.dtype)), "%s: state %s" % (where, k)
+            elif k in ("int_x", "int_y", "int_vx", "int_vy", "own_x", "own_y"):
+                prom = want["int_promoted"].astype(bool) if k in ("int_x", "int_y") else np.zeros(w.shape, bool)
+                ulp = np.where(prom, 1e-9 * np.maximum(1.0, np.abs(w)), np.spacing(np.abs(w).astype(np.float32)).astype(np.float64))
+                assert (np.abs(g.astype(np.float64) - w) <= np.maximum(ulp, 1e-9)).all(), "%s: state %s, max |d| = %g" % (
+                    where, k, np.abs(g.astype(np.float64) - w).max())
+            else:
+                assert (np.abs(g - w) <= 1e-9 * np.maximum(1.0, np.abs(w))).all(), "%s: state %s" % (where, k)
 
     close(env.reset().cpu().numpy()[0], fx["obs0"], name + " reset obs")
     inj = gu.prefixed_state(fx, "inj_")
@@ -118,10 +146,69 @@ def test_gpu_replays_reference_fixture_from_seed(uamenv, name):
         assert int(env.no_conflict[0].item()) == int(fx["no_conflict"][t]), where + ": no_conflict"
         if fx["done"][t]:
             close(env.reset().cpu().numpy()[0], fx["reset_obs"][reset_steps[t]], where + " reset obs")
+        check_snapshot(t, where)           # the fixtures snapshot the state AFTER the reset that follows a done step
         if t % 16 == 0 or fx["done"][t]:
             st = env.get_state(["int_conflict", "int_promoted"])
             assert np.array_equal(st["int_conflict"][0], fx["conflict"][t]), where + ": conflict flags"
             assert np.array_equal(st["int_promoted"][0], fx["promoted"][t]), where + ": promoted flags"
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal"])
+def test_benchmarked_instance_replays_deterministic_reference_fixtures(uamenv, name):
+    """The instance bench.py times (Philox, float32 positions, lean spawn) against the REFERENCE directly, no oracle in
+    between: G3 / G4 / G5 are deterministic (sigmas zero, state injected after reset(), no promoted intruder), so up to
+    the first episode end nothing depends on the random stream except the slot a respawn refills.  done / info /
+    no_conflict / conflict flags bit-exact, float32 intruder state bit-exact, observation and reward <= 1e-5."""
+    fx = gu.load(name)
+    N = int(fx["meta_N"])
+    assert not fx["inj_int_promoted"].any()
+    env = uamenv.BatchedSingleAircraftEnv(1, N, variant="discrete9", rng="philox", precision="f32", seed=5,
+                                          auto_reset=False, heading_sigma=float(fx["meta_heading_sigma"]),
+                                          speed_sigma=float(fx["meta_speed_sigma"]))
+    env.reset()
+    inj = gu.prefixed_state(fx, "inj_")
+    env.set_state({k: v for k, v in inj.items() if k not in ("int_speed", "int_heading")})
+    prev_vx = inj["int_vx"][0]
+    respawned = np.zeros(N, bool)          # slots the reference refilled from ITS stream: not comparable afterwards
+    steps = 0
+    for t in range(len(fx["actions"])):
+        obs, rew, done, infos = env.step(fx["actions"][t:t + 1])
+        where = "%s step %d" % (name, t)
+        if not fx["done"][t]:
+            st_vx = fx["st_int_vx"][t]
+            respawned |= st_vx != prev_vx
+            prev_vx = st_vx
+        assert bool(done[0].item()) == bool(fx["done"][t]), where + ": done"
+        assert int(infos.codes[0].item()) == int(fx["info"][t]), where + ": info"
+        assert int(env.no_conflict[0].item()) == int(fx["no_conflict"][t]), where + ": no_conflict"
+        assert abs(float(rew[0].item()) - fx["reward"][t]) <= 1e-5, where + ": reward"
+        st = env.get_state(["int_x", "int_y", "int_vx", "int_vy", "int_conflict", "int_promoted", "own_x", "own_y"])
+        if not fx["done"][t]:
+            assert np.array_equal(st["int_conflict"][0], fx["conflict"][t]), where + ": conflict flags"
+        assert not st["int_promoted"].any()
+        keep = ~respawned
+        if not fx["done"][t]:              # (a done step's snapshot is the reference's state after ITS reset)
+            for k in ("int_x", "int_y", "int_vx", "int_vy"):
+                assert np.array_equal(st[k][0][keep].astype(np.float32), fx["st_" + k][t][keep].astype(np.float32)), where + ": " + k
+            for k in ("own_x", "own_y"):  # float32(float64 position + fp64 velocity): device sincos vs glibc, <= 1 ulp
+                assert abs(float(st[k][0]) - float(fx["st_" + k][t])) <= float(np.spacing(np.float32(abs(fx["st_" + k][t])))), where + ": " + k
+        o = obs.cpu().numpy()[0].astype(np.float64)
+        mask = np.ones(4 * N + 8, bool)
+        for i in np.nonzero(respawned)[0]:
+            mask[4 * i:4 * i + 4] = False
+        assert np.abs(o - fx["obs"][t])[mask].max() <= 1e-5, where + ": obs"
+        steps += 1
+        if fx["done"][t]:
+            break                          # the next episode starts from the reference's stream
+    assert steps >= 1 and (name != "g4_respawn_in_conflict" or respawned.sum() == 1)
+    if name == "g3_nmac_early_exit":       # intruders after the colliding one were not integrated (:167-168), the others were
+        k = 3
+        assert np.array_equal(st["int_x"][0][k + 1:].astype(np.float32), inj["int_x"][0][k + 1:].astype(np.float32))
+        assert np.array_equal(st["int_x"][0][:k + 1].astype(np.float32),
+                              (inj["int_x"][0][:k + 1].astype(np.float32) + inj["int_vx"][0][:k + 1]).astype(np.float32))
+    if name == "g5_conflict_masks_goal":
+        assert list(fx["info"][:steps]) == [1, 1, 1, 2] and bool(fx["done"][steps - 1])
     env.close()
 
 
@@ -574,3 +661,109 @@ def test_step_many_single_launch_equals_single_steps(uamenv, variant, B, N, K):
     if variant == "her3":
         assert torch.equal(a.nearest(), b.nearest())
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------- BASELINE configs 4 and 5 at their stated shapes
+def test_config4_continuous_65536x32_sharded_8_ways_matches_oracle(uamenv, oracle):
+    """BASELINE.json configs[3]: SingleAircraft2Env continuous, ONE batch of 65536 x 32 partitioned 8192 per GPU.  On
+    the one-GPU box the eight shards are eight handles (env_id_offset = first global env), each stepping its chunk
+    the way a rank of the 8-GPU run does (uam_rollout: one looped launch per chunk); their union, and one unsharded
+    65536-env handle stepped launch by launch, must both equal the threaded oracle over the whole batch: flags and
+    rewards bit-exact, observations within 1e-6, the whole float state bit-exact."""
+    import torch
+    from uamenv.sharded import shard_bounds
+    B, N, K, W = 65536, 32, 10, 8
+    whole = uamenv.BatchedSingleAircraftEnv(B, N, variant="continuous", seed=404)
+    ocfg = pu.oracle_cfg_from(oracle, whole.cfg)
+    orc = oracle.OracleBatch(ocfg, oracle.MATH_PORTABLE, threads=16)
+    spans = [shard_bounds(B, W, r) for r in range(W)]
+    shards = [uamenv.BatchedSingleAircraftEnv(c, N, variant="continuous", seed=404, env_id_offset=f) for f, c in spans]
+    assert all(c == 8192 for _, c in spans) and all(s.steps_per_launch(K) == K for s in shards)
+    assert whole.steps_per_launch(K) == 1
+    o0 = whole.reset().cpu().numpy()
+    oo0 = orc.reset()
+    assert np.abs(o0 - oo0).max() <= 1e-6
+    for s, (f, c) in zip(shards, spans):
+        assert torch.equal(s.reset(), whole._obs[f:f + c])
+    rs = np.random.RandomState(12)
+    ost = orc.get_state()
+    # fly the batch into mid-episode first (conflicts, goals, NMACs, respawns all occur), unsharded vs oracle; the
+    # shards then take over the state of their slice — exactly what a checkpointed sharded run would do
+    for t in range(160):
+        a = pu.goal_seek_actions(ost, whole.cfg.d_heading, 2)
+        o, r, d, inf = whole.step(a)
+        oo = orc.step(a, want_obs=False)
+        assert np.array_equal(d.cpu().numpy().astype(np.uint8), oo[2]) and np.array_equal(inf.codes.cpu().numpy(), oo[3]), t
+        ost = orc.get_state()
+    wst = whole.get_state()
+    pu.compare_states(wst, ost, "config 4, unsharded, after the warm-up")
+    for s, (f, c) in zip(shards, spans):
+        s.set_state({k: (v if k == "step_index" else np.ascontiguousarray(v[f:f + c])) for k, v in wst.items()})
+    tape = np.zeros((K, B), dtype=np.float32)
+    orew, odone, oinfo = [], [], []
+    for k in range(K):
+        a = pu.goal_seek_actions(ost, whole.cfg.d_heading, 2)
+        m = rs.uniform(size=B) < 0.3
+        a[m] = rs.uniform(-1, 1, size=int(m.sum())).astype(np.float32)
+        tape[k] = a
+        o, r, d, inf = whole.step(a)
+        oo = orc.step(a)
+        pu.compare_outputs((o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), inf.codes.cpu().numpy()), oo, "config 4 step %d" % k, 1e-6)
+        orew.append(oo[1].astype(np.float32)); odone.append(oo[2]); oinfo.append(oo[3])
+        ost = orc.get_state()
+    pu.compare_states(whole.get_state(), ost, "config 4, unsharded, after %d steps" % K)
+    orew, odone, oinfo = np.stack(orew), np.stack(odone), np.stack(oinfo)
+    assert (oinfo == 1).any() and (oinfo == 2).any() and odone.any(), "the chunk should see conflicts, goals and resets"
+    tape_d = torch.from_numpy(tape).to(whole.device)
+    for s, (f, c) in zip(shards, spans):
+        rew = torch.empty((K, c), dtype=torch.float32, device=s.device)
+        done = torch.empty((K, c), dtype=torch.uint8, device=s.device)
+        info = torch.empty((K, c), dtype=torch.uint8, device=s.device)
+        obs = s.rollout_into(tape_d[:, f:f + c].contiguous(), rew, done, info)
+        assert np.array_equal(rew.cpu().numpy(), orew[:, f:f + c]) and np.array_equal(done.cpu().numpy(), odone[:, f:f + c])
+        assert np.array_equal(info.cpu().numpy(), oinfo[:, f:f + c])
+        assert torch.equal(obs[0], whole._obs[f:f + c])               # the chunk's last observation
+        sst = s.get_state()
+        for key in pu.STATE_EXACT:
+            if key in ("step_index",):
+                continue
+            assert np.array_equal(sst[key], np.asarray(ost[key])[f:f + c].astype(sst[key].dtype)), (f, key)
+        s.close()
+    whole.close(); orc.close()
+
+
+def test_config5_randintruder_8192x64_steps_and_one_mcts_plan_match_oracle(uamenv, oracle):
+    """BASELINE.json configs[4]: SingleAircraftMCTSRandIntruderEnv, 8192 envs x 64 intruders, driven by the MCTS
+    planner (Algorithms/MCTS/Agent_RandInt.py:25-46).  Five lockstep steps against the oracle at the full shape; the
+    first action of every env comes from ONE batched best_action(100, 3) over all 8192 roots, checked against the
+    oracle's search on a sample of roots (child visit counts, q and the chosen action bit-exact)."""
+    import torch
+    B, N = 8192, 64
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=77)
+    ocfg = pu.oracle_cfg_from(oracle, env.cfg)
+    orc = oracle.OracleBatch(ocfg, oracle.MATH_PORTABLE, threads=16)
+    go, oo = env.reset().cpu().numpy(), orc.reset()
+    assert (np.abs(go - oo) <= 1e-6 * np.maximum(1.0, np.abs(oo))).all()
+    planner = uamenv.BatchedMCTS(N, seed=7, simulations=100, search_depth=3)
+    roots = planner.roots_from_env(env)
+    acts, cq, cn = planner.best_action(roots, root_id0=0, want_children=True)
+    torch.cuda.synchronize()
+    roots_h, acts_h, cq_h, cn_h = roots.cpu().numpy(), acts.cpu().numpy(), cq.cpu().numpy(), cn.cpu().numpy()
+    assert acts_h.shape == (B, 2) and ((acts_h >= 0) & (acts_h <= 2)).all()
+    mo = oracle.UamMctsConfig()
+    for name, _ in oracle.UamMctsConfig._fields_:
+        setattr(mo, name, getattr(planner.cfg, name))
+    for k in (0, 1, 511, 4095, 4096, 8191) + tuple(np.random.RandomState(3).randint(0, B, 10)):
+        o = oracle.mcts_best_action(mo, roots_h[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE, root_id=int(k))
+        assert np.array_equal(cn_h[k], o["child_n"]) and np.array_equal(cq_h[k], o["child_q"]), k
+        assert np.array_equal(acts_h[k], o["best_action"]), k
+    rs = np.random.RandomState(8)
+    a = acts_h.astype(np.int32)
+    for t in range(5):
+        o, r, d, inf = env.step(a)
+        oo = orc.step(a)
+        pu.compare_outputs((o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), inf.codes.cpu().numpy()), oo,
+                           "config 5 step %d" % t, 1e-6)
+        a = pu.random_actions(rs, B, 1)
+    pu.compare_states(env.get_state(), orc.get_state(), "config 5 after 5 steps", hold_sh=True)
+    env.close(); orc.close()

@@ -9,7 +9,9 @@ import golden_util as gu
 
 MOVE_FIXTURES = ["g11_mcts_move_n8", "g11_mcts_move_n20", "g11_mcts_move_n8_flags", "g11_mcts_move_n8_noisy",
                  # the 4-wide model of Algorithms/MCTS/nodes_single.py (Agent.py's planner)
-                 "g16_mcts4_move_n8", "g16_mcts4_move_n20", "g16_mcts4_move_n8_flags", "g16_mcts4_move_n8_noisy"]
+                 "g16_mcts4_move_n8", "g16_mcts4_move_n20", "g16_mcts4_move_n8_flags", "g16_mcts4_move_n8_noisy",
+                 # every sigma zero: the cases the GPU is compared with DIRECTLY (tests/test_gpu_mcts.py)
+                 "g18_mcts4_move_zero_n8", "g18_mcts4_move_zero_n20", "g18_mcts4_move_zero_n8_flags"]
 SEARCH_FIXTURES = ["g12_mcts_search_n8", "g12_mcts_search_n20", "g12_mcts_search_n8_flags",
                    "g17_mcts4_search_n8", "g17_mcts4_search_n20"]
 
@@ -22,6 +24,8 @@ def _cfg(oracle, fx, name):
     over = {}
     if name.endswith("noisy"):
         over = dict(position_sigma=10 / 30, speed_sigma=2 / 30)
+    if "_zero_" in name:
+        over = dict(position_sigma=0.0, speed_sigma=0.0, heading_sigma=0.0)
     return oracle.mcts_config(int(fx["meta_N"]), model=_model(fx), **over)
 
 
