@@ -49,8 +49,8 @@
 #endif
 #if UAM_STAMP
 #define UAM_NSTAMP 10
-#define UAM_STAMP_AT(i) do { if constexpr (PERSIST) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-    stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } } while (0)
+#define UAM_STAMP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define UAM_STAMP_AT(i) do { } while (0)
 #endif
@@ -73,6 +73,12 @@
 #define UAM_MANY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_MANY_WAVES_PER_EU, 8)))
 #else
 #define UAM_MANY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK)
+#endif
+
+#if defined(UAM_HEAVY_WAVES_PER_EU)
+#define UAM_HEAVY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_HEAVY_WAVES_PER_EU, 8)))
+#else
+#define UAM_HEAVY_BOUNDS __launch_bounds__(UAM_MAX_BLOCK)
 #endif
 
 /* device pointers of the struct-of-arrays env state (HBM) */
@@ -145,6 +151,8 @@ struct UamParams {
     const uint8_t* mask;
     int32_t many_K;               /* uam_sweep_many_kernel: steps per launch; actions / reward / done / info / noise advance by */
     int32_t act_step_words;       /* act_step_words 32-bit words resp. B elements per step */
+    int32_t mt_win;               /* MT19937 step kernel: capacity in words of the per-env stream window in LDS (<= 224) */
+    int32_t mt_first;             /* words of it twisted ahead at the head of every step (a cooperative refill takes mt_win) */
     int32_t obs_direct;           /* uam_sweep_many_kernel: 1 = rows leave straight from registers (no LDS staging) */
     int32_t obs_slots;            /* uam_sweep_many_kernel: 0 = only the last step emits the observation (into obs);
                                      R > 0 = step k emits its observation into slot k % R of obs[R][B][D] (uam_rollout) */
@@ -206,10 +214,29 @@ __device__ __forceinline__ double uam_u53_open0(uint32_t a, uint32_t b)
  * at consumption time (identical sequence: word k of a round only depends on
  * words k, k+1 and k+397 mod 624 in their state at that moment), so a draw
  * costs 3 loads + 1 store and there is no 624-word stall. */
+/* an LDS pointer that stays an LDS pointer inside a struct (a generic pointer would turn every window read into a
+ * flat_load, which waits for ALL outstanding vector-memory and LDS operations) */
+typedef const __attribute__((address_space(3))) uint32_t* UAM_LDS_U32;
+
 struct MtCtx {
     uint32_t* key;
     int pos, gen, has_gauss;
     double gauss;
+    /* the step kernel's per-env window (LDS): TEMPERED outputs of words [win_base, win_base + win_len) of the
+     * current round, twisted ahead by the env's lane group (mt_window_fill); empty everywhere else */
+    UAM_LDS_U32 win;
+    int win_base, win_len;
+    /* cooperative refill (lane-group contexts only; cap = 0 elsewhere): when the window runs out, the group's L lanes
+     * twist the next `cap` words together instead of drawing them one dependent memory round trip at a time */
+    int cap, gl, L;
+};
+
+/* per-env header of the window in LDS (8 words): the stream cursor travels through it from the lane group (fill)
+ * to the env's ownship thread (two normals) and back to the lane group (respawns, heading changes, reset) */
+struct MtHdr {
+    int pos, gen, has_gauss, win_base;
+    double gauss;
+    int win_len, pad;
 };
 
 __device__ __forceinline__ void mt_load(const UamDev& s, int e, MtCtx& m)
@@ -219,6 +246,26 @@ __device__ __forceinline__ void mt_load(const UamDev& s, int e, MtCtx& m)
     m.gen = s.mt_gen[e];
     m.has_gauss = s.mt_has_gauss[e];
     m.gauss = s.mt_gauss[e];
+    m.win = (UAM_LDS_U32)0; m.win_base = 0; m.win_len = 0; m.cap = 0; m.gl = 0; m.L = 1;
+}
+__device__ __forceinline__ void mt_load_lds(const UamDev& s, int e, const MtHdr* h, const uint32_t* win, MtCtx& m)
+{
+    m.key = s.mt_key + (size_t)e * UAM_MT_N;
+    m.pos = h->pos; m.gen = h->gen; m.has_gauss = h->has_gauss; m.gauss = h->gauss;
+    m.win = (UAM_LDS_U32)win; m.win_base = h->win_base; m.win_len = h->win_len; m.cap = 0; m.gl = 0; m.L = 1;
+}
+__device__ __forceinline__ void mt_store_lds(MtHdr* h, const MtCtx& m)
+{
+    h->pos = m.pos; h->gen = m.gen; h->has_gauss = m.has_gauss; h->gauss = m.gauss;
+    h->win_len = m.win_len;      /* 0 once the cursor has left the window's round */
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t v)
+{
+    v ^= (v >> 11);
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= (v >> 18);
+    return v;
 }
 __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
 {
@@ -228,27 +275,125 @@ __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
     s.mt_gauss[e] = m.gauss;
 }
 
-__device__ inline uint32_t mt_u32(MtCtx& m)
+/* Twist words [pos, pos + len) of the current round in parallel across the L lanes of a group (lane gl) and leave
+ * their TEMPERED outputs in win[0 .. len): word k of a round depends on key[k], key[k+1] (both still in the previous
+ * round's state while k >= gen) and key[(k+397) mod 624] (previous round's state for k < 227, else a word of this
+ * round at least 227 places back), so any <= 227 consecutive words of one round are independent of each other.
+ * Chunks of 4 L words: all of a chunk's loads are issued before its first store, so a lane pays one memory round trip
+ * per chunk, not one per word (vmcnt is in-order: a load behind a store would wait for that store); a later chunk
+ * never reads a word an earlier one wrote. */
+typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32W;
+__device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, const int gen, const int len, const int gl,
+                                              const int L, UAM_LDS_U32W win)
 {
-    if (m.pos >= UAM_MT_N) { m.pos = 0; m.gen = 0; }
-    const int pos = m.pos;
+    for (int i0 = 0; i0 < len; i0 += 4 * L) {
+        uint32_t a[4], b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * L + gl, k = pos + i;
+            a[u] = 0; b[u] = 0; c[u] = 0;
+            if (i < len) {
+                a[u] = key[k];
+                if (k >= gen) {
+                    int p1 = k + 1; if (p1 == UAM_MT_N) p1 = 0;
+                    int pm = k + UAM_MT_M; if (pm >= UAM_MT_N) pm -= UAM_MT_N;
+                    b[u] = key[p1]; c[u] = key[pm];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * L + gl, k = pos + i;
+            if (i < len) {
+                uint32_t v = a[u];
+                if (k >= gen) {
+                    const uint32_t y = (a[u] & 0x80000000u) | (b[u] & 0x7fffffffu);
+                    v = c[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                    key[k] = v;
+                }
+                win[i] = mt_temper(v);
+            }
+        }
+    }
+}
+
+/* The two slow paths of a draw are real functions (noinline, everything passed and returned in registers): a draw is
+ * inlined at ~30 places, and with these bodies inlined too the MT19937 step kernel grew to 15 k instructions (~100 KB),
+ * past the instruction cache — every wave then streamed its code from L2 and a step took 40 us even on an idle chip. */
+struct MtRefillOut { int pos, gen, len; };
+struct MtWordOut { uint32_t v; int pos, gen; };
+
+/* lane-group context: every lane of the group is here with the same cursor (the draws of a group are uniform), so the
+ * group refills its window together — a reset draws 8 N words; one dependent memory round trip per word made that
+ * wave a 100 us straggler that set the whole launch's time */
+__device__ __attribute__((noinline)) MtRefillOut mt_refill_fn(uint32_t* key, int pos, int gen, int cap, int gl, int L, UAM_LDS_U32W win)
+{
+    if (pos >= UAM_MT_N) { pos = 0; gen = 0; }
+    const int len = min(cap, UAM_MT_N - pos);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      /* earlier reads of the old window are done */
+    __builtin_amdgcn_wave_barrier();
+    mt_twist_span(key, pos, gen, len, gl, L, win);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    MtRefillOut r;
+    r.pos = pos; r.gen = max(gen, pos + len); r.len = len;
+    return r;
+}
+
+/* single-lane contexts (the ownship thread past its window, the reset kernel): one word at a time */
+__device__ __attribute__((noinline)) MtWordOut mt_word_fn(uint32_t* key, int pos, int gen)
+{
+    if (pos >= UAM_MT_N) { pos = 0; gen = 0; }
     uint32_t v;
-    if (pos >= m.gen) {
+    if (pos >= gen) {
         int p1 = pos + 1; if (p1 == UAM_MT_N) p1 = 0;
         int pm = pos + UAM_MT_M; if (pm >= UAM_MT_N) pm -= UAM_MT_N;
-        uint32_t y = (m.key[pos] & 0x80000000u) | (m.key[p1] & 0x7fffffffu);
-        v = m.key[pm] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-        m.key[pos] = v;   /* every lane of a group stores the same word: benign, keeps per-thread program order */
-        m.gen = pos + 1;
+        const uint32_t y = (key[pos] & 0x80000000u) | (key[p1] & 0x7fffffffu);
+        v = key[pm] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        key[pos] = v;   /* every lane of a group stores the same word: benign, keeps per-thread program order */
+        gen = pos + 1;
     } else {
-        v = m.key[pos];
+        v = key[pos];
     }
-    m.pos = pos + 1;
-    v ^= (v >> 11);
-    v ^= (v << 7) & 0x9d2c5680u;
-    v ^= (v << 15) & 0xefc60000u;
-    v ^= (v >> 18);
-    return v;
+    MtWordOut r;
+    r.v = mt_temper(v); r.pos = pos + 1; r.gen = gen;
+    return r;
+}
+
+__device__ __forceinline__ uint32_t mt_u32(MtCtx& m)
+{
+    const int wi = m.pos - m.win_base;
+    if (wi >= 0 && wi < m.win_len) { m.pos++; return m.win[wi]; }   /* served from the window: an LDS read, already tempered */
+    if (m.cap > 0) {
+        const MtRefillOut r = mt_refill_fn(m.key, m.pos, m.gen, m.cap, m.gl, m.L, (UAM_LDS_U32W)m.win);
+        m.win_base = r.pos; m.win_len = r.len; m.gen = r.gen;
+        m.pos = r.pos + 1;
+        return m.win[0];
+    }
+    /* new round: the window belongs to the round it was twisted in */
+    if (m.pos >= UAM_MT_N) m.win_len = 0;
+    const MtWordOut w = mt_word_fn(m.key, m.pos, m.gen);
+    m.pos = w.pos; m.gen = w.gen;
+    return w.v;
+}
+
+/* The env's lane group twists the first window of a step AHEAD, in parallel, and leaves it in LDS with the stream's
+ * cursor: the ownship thread (another wave) draws its two normals from it, then the group carries on.  A draw costs an
+ * LDS read instead of three dependent, uncoalesced global loads and a store per word.  The window stops at the end of
+ * the round. */
+__device__ __forceinline__ void mt_window_fill(const UamDev& s, const int e, const int gl, const int L, const int W,
+                                               uint32_t* win, MtHdr* hdr)
+{
+    uint32_t* key = s.mt_key + (size_t)e * UAM_MT_N;
+    int pos = s.mt_pos[e], gen = s.mt_gen[e];
+    if (pos >= UAM_MT_N) { pos = 0; gen = 0; }
+    const int len = min(W, UAM_MT_N - pos);
+    mt_twist_span(key, pos, gen, len, gl, L, (UAM_LDS_U32W)win);
+    if (gl == 0) {
+        hdr->pos = pos; hdr->gen = max(gen, pos + len); hdr->has_gauss = s.mt_has_gauss[e]; hdr->gauss = s.mt_gauss[e];
+        hdr->win_base = pos; hdr->win_len = len;
+    }
 }
 
 __device__ inline double mt_double(MtCtx& m)
@@ -313,12 +458,35 @@ template <> struct Rng<UAM_RNG_MT19937> {
     uint32_t gid, c_step, c_reset, k0, k1; /* unused */
     __device__ __forceinline__ void load(const UamDev& s, int e) { mt_load(s, e, m); }
     __device__ __forceinline__ void store(const UamDev& s, int e) { mt_store(s, e, m); }
+    __device__ __forceinline__ void load_lds(const UamDev& s, int e, const MtHdr* h, const uint32_t* win) { mt_load_lds(s, e, h, win, m); }
+    /* When the next 8 (4) words are all in the window, take them with independent LDS reads issued together instead of
+     * eight (four) read -> wait -> combine rounds: a reset draws 8 N words back to back */
+    __device__ __forceinline__ static double dbl(uint32_t a, uint32_t b)
+    {
+        return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
+    }
     __device__ __forceinline__ void quad(bool, uint32_t, uint32_t, double* u)
     {
+        const int wi = m.pos - m.win_base;
+        if (wi >= 0 && wi + 8 <= m.win_len) {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = m.win[wi + i];
+            m.pos += 8;
+            u[0] = dbl(w[0], w[1]); u[1] = dbl(w[2], w[3]); u[2] = dbl(w[4], w[5]); u[3] = dbl(w[6], w[7]);
+            return;
+        }
         u[0] = mt_double(m); u[1] = mt_double(m); u[2] = mt_double(m); u[3] = mt_double(m);
     }
     __device__ __forceinline__ void two(bool, uint32_t, uint32_t, uint32_t, double& u1, double& u2)
     {
+        const int wi = m.pos - m.win_base;
+        if (wi >= 0 && wi + 4 <= m.win_len) {
+            const uint32_t a = m.win[wi], b = m.win[wi + 1], c = m.win[wi + 2], d = m.win[wi + 3];
+            m.pos += 4;
+            u1 = dbl(a, b); u2 = dbl(c, d);
+            return;
+        }
         u1 = mt_double(m);
         u2 = mt_double(m);
     }
@@ -446,6 +614,46 @@ __device__ __forceinline__ bool too_close(float ox, float oy, typename PosT<POS6
     }
     float dx = ox - (float)x, dy = oy - (float)y;
     return dx * dx + dy * dy < p.init2_32;
+}
+
+/* The two halves of the non-lean spawn, for the MT19937 paths: the DRAWS of a spawn are sequential in the env's
+ * stream (every lane of the group takes them), but the float32 velocity needs fp64 trig that only the lane owning
+ * the slot has to compute, after the last draw.  spawn_draw = the uniforms, the position and its rejection redraws;
+ * spawn_velocity = Aircraft.__init__'s float32(speed * (cos, sin)(heading)) (:275-277). */
+template <bool POS64, int RNG>
+__device__ inline void spawn_draw(const UamParams& p, Rng<RNG>& rng, uint32_t idx, bool reset_phase, float ox, float oy,
+                                  typename PosT<POS64>::type& X, typename PosT<POS64>::type& Y, bool& prom, double& sp,
+                                  double& hd)
+{
+    typedef typename PosT<POS64>::type P;
+    const uint32_t purpose = reset_phase ? UAM_PH_RESET_SPAWN : UAM_PH_SPAWN;
+    double u[4];
+    rng.quad(reset_phase, purpose, idx, u);
+    double fx = 0.0 + p.c->W * u[0], fy = 0.0 + p.c->H * u[1];
+    sp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
+    hd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
+    X = (P)(float)fx;
+    Y = (P)(float)fy;
+    prom = false;
+    uint32_t attempt = 0;
+    while (too_close<POS64>(ox, oy, X, Y, prom, p)) {
+        attempt++;
+        double u1, u2;
+        rng.two(reset_phase, purpose, idx, attempt, u1, u2);
+        fx = 0.0 + p.c->W * u1;
+        fy = 0.0 + p.c->H * u2;
+        if (POS64) { X = (P)fx; Y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
+        else { X = (P)(float)fx; Y = (P)(float)fy; }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void spawn_velocity(double sp, double hd, float& vx, float& vy)
+{
+    double sn, cs;
+    sincos_sel<KC>(hd, &sn, &cs);
+    vx = (float)(sp * cs);
+    vy = (float)(sp * sn);
 }
 
 /* reset_intruder / spawn loop of reset(): SingleAircraftEnv.py:79-86, 230-251, 270-279.
@@ -862,11 +1070,21 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
             }
         }
     } else {
+        /* the stream is sequential: every lane takes every intruder's draws; the owner of the slot keeps them and
+         * does the fp64 trig for its own four slots afterwards (lane-parallel, 4 sincos per lane instead of N) */
+        double spv[4] = {0.0, 0.0, 0.0, 0.0}, hdv[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = 0; i < p.N; i++) {
-            typename PosT<POS64>::type X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN, KC>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, vx, vy, sp, hd);
-            if ((i >> 2) == gl) q.set(i & 3, X, Y, prom, vx, vy, sp, hd);
+            typename PosT<POS64>::type X, Y; bool prom; double sp, hd;
+            spawn_draw<POS64, RNG>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, sp, hd);
+            if ((i >> 2) == gl) {
+                q.set(i & 3, X, Y, prom, 0.f, 0.f, sp, hd);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j == (i & 3)) { spv[j] = sp; hdv[j] = hd; }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (quad_ok && 4u * gl + j < (uint32_t)p.N) spawn_velocity<KC>(spv[j], hdv[j], q.vx[j], q.vy[j]);
     }
     double g1, g2;
     rng.two(true, UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
@@ -998,7 +1216,8 @@ __device__ __forceinline__ void own_update(const UamParams& p, const UamCold& c,
  * written out so that this kernel's register allocation (63 VGPRs, 8 waves/SIMD) does not depend on the looped
  * kernel's needs; tests/test_gpu_rollout.py and the step_many tests hold the two forms bit-identical. */
 template <int RNG, bool KC = false>
-__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh, const int k = 0)
+__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh, const int k = 0,
+                                            MtHdr* mt_hdr = nullptr, const uint32_t* mt_win = nullptr)
 {
     /* the cold configuration arrives BY VALUE (kernarg, scalar loads, no aliasing with the stores
      * below); every input is loaded up front so the thread pays one memory round trip, not five */
@@ -1020,11 +1239,12 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
         const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
         zh = z.x; zs = z.y;
     } else {
+        /* the stream cursor and the words twisted ahead by the env's lane group are in LDS (mt_window_fill) */
         Rng<UAM_RNG_MT19937> rng;
-        rng.load(p.s, e);
+        rng.load_lds(p.s, e, mt_hdr, mt_win);
         zh = mt_gauss(rng.m);   /* nothing else draws between the two normals */
         zs = mt_gauss(rng.m);
-        rng.store(p.s, e);
+        mt_store_lds(mt_hdr, rng.m);
     }
     double a0, a1;
     bool has_speed = true;
@@ -1102,6 +1322,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
 {
 #if UAM_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp_local[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!PERSIST) stamp_acc = stamp_local;
 #endif
     Quad<POS64, SH> q_local;
     Quad<POS64, SH>& q = PERSIST ? q_persist : q_local;
@@ -1121,6 +1343,9 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     /* [E][3] float4 of ownship records, then the obs staging; the looped kernel passes its own (it alternates two
      * record sets and its ownship wave has already filled this step's, behind a block barrier) */
     float4* lds_share = PERSIST ? rec_persist : (float4*)lds_raw;
+    /* MT19937 only: per-env stream headers and windows behind the records and the obs staging */
+    MtHdr* const mt_hdr_base = (MtHdr*)(lds_raw + (size_t)p.E * 48 + (p.obs_vec ? (size_t)p.E * p.D * 4 : 0));
+    uint32_t* const mt_win_base = (uint32_t*)(mt_hdr_base + p.E);
     if constexpr (PERSIST) {
         if (env_first >= p.B) return;
     } else {
@@ -1128,12 +1353,22 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
          * quad never share the register file (keeps the kernel at 64 VGPRs = 8 waves/SIMD); every
          * other thread has its loads in flight while it waits at the barrier */
         const bool does_own = tid < p.E;
+        if constexpr (RNG == UAM_RNG_MT19937) {
+            /* every lane group twists its env's next window of the NumPy stream ahead, into LDS; one barrier later
+             * the ownship threads draw their normals from it */
+            if (env_ok) mt_window_fill(p.s, env, gl, L, p.mt_first, mt_win_base + (size_t)g * p.mt_win, mt_hdr_base + g);
+            __syncthreads();
+        }
         if (!does_own) quad_load<POS64, SH>(p, base, quad_ok, q);
         if (does_own) {
             const int e = blockIdx.x * p.E + tid;
             /* cold configuration through the pointer: its scalar loads (and SGPRs) stay inside this branch */
             const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();   /* see `pk` below */
-            if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k);
+            if constexpr (RNG == UAM_RNG_MT19937) {
+                if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k, mt_hdr_base + tid, mt_win_base + (size_t)tid * p.mt_win);
+            } else {
+                if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k);
+            }
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();
@@ -1237,6 +1472,14 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     Rng<RNG> rng;
     bool vel_dirty = false;
     bool mt_used = false;
+    if constexpr (RNG == UAM_RNG_MT19937) {
+        /* the cursor as the ownship thread left it; every lane of the group draws the same words from here on */
+        if (env_ok) {
+            rng.load_lds(p.s, env, mt_hdr_base + g, mt_win_base + (size_t)g * p.mt_win);
+            rng.m.cap = p.mt_win; rng.m.gl = gl; rng.m.L = L;     /* the group refills its window together */
+            mt_used = true;
+        }
+    }
 
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
@@ -1253,19 +1496,29 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
+        uint32_t pend = 0;                  /* my slots whose velocity is still to be computed */
+        double spv[4] = {0.0, 0.0, 0.0, 0.0}, hdv[4] = {0.0, 0.0, 0.0, 0.0};
         for (;;) {
             const uint32_t mine = resp ? 4u * gl + (uint32_t)(__ffs((int)resp) - 1) : 0xFFFFu;
             const uint32_t nxt = grp_min(mine, L);
             if (nxt == 0xFFFFu) break;
             if (!mt_used) { rng.load(p.s, env); mt_used = true; }
-            P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN, KC>(p, rng, nxt, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            P X, Y; bool prom; double sp, hd;
+            spawn_draw<POS64, RNG>(p, rng, nxt, false, ox, oy, X, Y, prom, sp, hd);
             if (mine == nxt) {
-                resp &= ~(1u << (nxt & 3u));
-                q.set((int)(nxt & 3u), X, Y, prom, vx, vy, sp, hd);
+                const uint32_t jj = nxt & 3u;
+                resp &= ~(1u << jj);
+                pend |= 1u << jj;
+                q.set((int)jj, X, Y, prom, 0.f, 0.f, sp, hd);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if ((uint32_t)j == jj) { spv[j] = sp; hdv[j] = hd; }
                 vel_dirty = true;
             }
         }
+        /* the trig of the respawned slots after the last draw, each lane for its own slots only */
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((pend >> j) & 1u) spawn_velocity<KC>(spv[j], hdv[j], q.vx[j], q.vy[j]);
     }
 
     UAM_STAMP_AT(3);
@@ -1440,6 +1693,25 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         }
     }
     UAM_STAMP_AT(8);
+#if UAM_STAMP
+    if (!PERSIST && p.actions_out && (threadIdx.x & 63) == 0) {     /* single-step kernel: one record per wave */
+        unsigned long long* dst = (unsigned long long*)p.actions_out + ((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * UAM_NSTAMP;
+        for (int i = 0; i < UAM_NSTAMP; i++) dst[i] = stamp_acc[i];
+    }
+#endif
+}
+
+/* the float64-position and MT19937 instances: fp64 spawn trig and the stream bookkeeping put them at ~3 waves/SIMD
+ * whatever the scalar budget, so they get all 102 SGPRs (no scalar spills, no scratch) instead of the 80-SGPR cap that
+ * keeps the lean instances at 8 waves/SIMD */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+__global__ void UAM_HEAVY_BOUNDS uam_sweep_heavy_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Quad<POS64, SH> q;
+    bool vd = false;
+    int32_t ncf = 0;
+    sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX), false>(p, lds_raw, 0, p.obs, q, vd, ncf);
 }
 
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>

@@ -34,13 +34,17 @@ static int fail(int code, const char* fmt, ...)
             return fail(UAM_EIO, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+typedef void (*UamSweepFn)(const UamParams);
+
 struct uam_env {
     uam_config cfg;
+    UamSweepFn step_kernel;     /* the handle's step-kernel instance */
     int device;
     int Np, Q, L, lshift, T, E, D, hold_sh;
     int num_cus;                /* compute units of the device (hipDeviceProp_t::multiProcessorCount) */
     int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
+    int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
     int Tm, Em;                 /* looped kernel: sweeping threads per block (+ 64 for its ownship wave), envs per block <= 64 */
     uint32_t step_index;        /* uam_step calls so far */
@@ -62,8 +66,9 @@ struct uam_env {
     uint32_t policy_calls;
 };
 
-typedef void (*UamSweepFn)(const UamParams);
 static UamSweepFn many_fn(const uam_env* e);
+static UamSweepFn step_fn(const uam_env* e);
+static inline size_t lds_step(const uam_env* e, bool staged);
 static bool many_instance_exists(const uam_env* e);
 static UamSweepFn many4_fn(const uam_env* e);
 static inline size_t lds_many(const uam_env* e, int fl, bool staged);
@@ -246,6 +251,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->nmac_pen32 = (float)c.nmac_penalty; p->conf_pen32 = (float)c.conflict_penalty;
     p->spawn_sx = (float)c.window_width * 0x1p-24f; p->spawn_sy = (float)c.window_height * 0x1p-24f;
     p->min_speed32 = (float)c.min_speed; p->vrange32 = (float)(c.max_speed - c.min_speed);
+    p->mt_win = e->mt_win; p->mt_first = e->mt_first;
 }
 
 static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
@@ -299,6 +305,21 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (T < 64) T = 64;
     e->T = T;
     e->E = T / L;
+    /* MT19937 window: a step draws ~5 words for the ownship's two normals and 8 per respawn (+ 4 per rejection
+     * redraw); RandIntruder adds 2 per intruder for the heading-change Bernoullis (+ 2 per change).  One round of
+     * the twist allows at most 227 independent words */
+    e->mt_win = 0; e->mt_first = 0;
+    if (cfg->rng_mode == UAM_RNG_MT19937) {
+        int w = 24 + (cfg->dynamics == UAM_DYN_RANDINTRUDER ? 2 * N + N / 4 : 0);
+        e->mt_first = w > 224 ? 224 : w;
+        e->mt_win = e->mt_first < 96 ? 96 : e->mt_first;      /* a reset draws 8 N words: refills of 96 */
+        if (const char* mw = getenv("UAMENV_MT_WIN")) {        /* development override: "first" or "first,capacity" */
+            int f = -1, c = -1;
+            const int n = sscanf(mw, "%d,%d", &f, &c);
+            if (n >= 1 && f >= 0 && f <= 224) { e->mt_first = f; if (e->mt_win < f) e->mt_win = f; }
+            if (n == 2 && c >= e->mt_first && c <= 224) e->mt_win = c;
+        }
+    }
     e->Tm = T < 64 * L ? T : 64 * L;      /* the ownship wave has one lane per env of the block */
     e->Em = e->Tm / L;
     e->D = uam_obs_dim(cfg);
@@ -357,6 +378,17 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
         if (!rc) rc = dev_alloc(e, &e->s.mt_gen, (size_t)B);
         if (!rc) rc = dev_alloc(e, &e->s.mt_has_gauss, (size_t)B);
         if (!rc) rc = dev_alloc(e, &e->s.mt_gauss, (size_t)B);
+    }
+    e->step_kernel = step_fn(e);
+    if (getenv("UAMENV_DEBUG")) {
+        int per_cu = -1;
+        hipFuncAttributes fa;
+        memset(&fa, 0, sizeof(fa));
+        (void)hipFuncGetAttributes(&fa, (const void*)e->step_kernel);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, e->step_kernel, e->T, lds_step(e, true));
+        fprintf(stderr, "[uamenv] step kernel: block %d, grid %d, LDS %zu B dynamic + %zu static, %d regs, %zu B scratch, "
+                "occupancy %d blocks/CU x %d CUs\n", e->T, grid_of(e), lds_step(e, true), (size_t)fa.sharedSizeBytes,
+                fa.numRegs, (size_t)fa.localSizeBytes, per_cu, e->num_cus);
     }
     e->many_resident_blocks = 0;
     e->many4_resident_blocks = 0;
@@ -437,30 +469,45 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
 }
 
 /* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held, random ownship start) ---- */
-template <bool POS64, int RNG, int RI, bool SH>
-static void launch_sweep_ros(const uam_env* e, const UamParams& p, hipStream_t st)
+/* the step kernel instance of a handle (every instance has the same signature) */
+template <bool POS64, int RNG, int MODE, bool SH>
+static UamSweepFn step_fn_ros(const uam_env* e)
 {
-    dim3 grid(grid_of(e)), block(e->T);
-    const size_t lds = lds_stage(e, p) + (size_t)e->E * 48;      /* obs staging + the ownship records */
-    if (e->cfg.random_own_start)
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, true>), grid, block, lds, st, p);
-    else
-        hipLaunchKernelGGL((uam_sweep_kernel<POS64, RNG, RI, SH, false>), grid, block, lds, st, p);
+    if constexpr (POS64 || RNG == UAM_RNG_MT19937) {
+        if (e->cfg.random_own_start) return uam_sweep_heavy_kernel<POS64, RNG, MODE, SH, true>;
+        return uam_sweep_heavy_kernel<POS64, RNG, MODE, SH, false>;
+    } else {
+        if (e->cfg.random_own_start) return uam_sweep_kernel<POS64, RNG, MODE, SH, true>;
+        return uam_sweep_kernel<POS64, RNG, MODE, SH, false>;
+    }
 }
 
 template <bool POS64, int RNG>
-static void launch_sweep_t(const uam_env* e, const UamParams& p, hipStream_t st)
+static UamSweepFn step_fn_t(const uam_env* e)
 {
     const bool knn = e->cfg.obs_mode == UAM_OBS_KNN5;       /* never with held speed/heading (validate) */
-    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) launch_sweep_ros<POS64, RNG, UAM_MODE_RI, true>(e, p, st);
-    else if (knn && e->cfg.shaped_reward) launch_sweep_ros<POS64, RNG, UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e, p, st);
-    else if (knn) launch_sweep_ros<POS64, RNG, UAM_MODE_KNN, false>(e, p, st);
-    else if (e->cfg.shaped_reward) {
-        if (e->hold_sh) launch_sweep_ros<POS64, RNG, UAM_MODE_SHAPED, true>(e, p, st);
-        else launch_sweep_ros<POS64, RNG, UAM_MODE_SHAPED, false>(e, p, st);
-    }
-    else if (e->hold_sh) launch_sweep_ros<POS64, RNG, 0, true>(e, p, st);
-    else launch_sweep_ros<POS64, RNG, 0, false>(e, p, st);
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) return step_fn_ros<POS64, RNG, UAM_MODE_RI, true>(e);
+    if (knn && e->cfg.shaped_reward) return step_fn_ros<POS64, RNG, UAM_MODE_KNN | UAM_MODE_SHAPED, false>(e);
+    if (knn) return step_fn_ros<POS64, RNG, UAM_MODE_KNN, false>(e);
+    if (e->cfg.shaped_reward) return e->hold_sh ? step_fn_ros<POS64, RNG, UAM_MODE_SHAPED, true>(e) : step_fn_ros<POS64, RNG, UAM_MODE_SHAPED, false>(e);
+    if (e->hold_sh) return step_fn_ros<POS64, RNG, 0, true>(e);
+    return step_fn_ros<POS64, RNG, 0, false>(e);
+}
+
+static UamSweepFn step_fn(const uam_env* e)
+{
+    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
+    if (x && mt) return step_fn_t<true, UAM_RNG_MT19937>(e);
+    if (x) return step_fn_t<true, UAM_RNG_PHILOX>(e);
+    if (mt) return step_fn_t<false, UAM_RNG_MT19937>(e);
+    return step_fn_t<false, UAM_RNG_PHILOX>(e);
+}
+
+/* LDS of one step-kernel block: obs staging + the ownship records (+ MT19937: per-env stream header and window) */
+static inline size_t lds_step(const uam_env* e, bool staged)
+{
+    return (staged ? (size_t)e->E * e->D * 4 : 0) + (size_t)e->E * 48 +
+           (e->cfg.rng_mode == UAM_RNG_MT19937 ? (size_t)e->E * (32 + 4 * (size_t)e->mt_win) : 0);
 }
 
 /* K steps in one launch (float32 / Philox instances only; everything else loops over single steps) */
@@ -565,14 +612,38 @@ static const int KTIMING_MAX = 256;
 
 static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
 {
-    const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
     const bool sample = e->ktiming && e->ksamples < KTIMING_MAX;
     hipEvent_t* ev = sample ? &e->kev[(size_t)3 * e->ksamples] : nullptr;
     if (sample) { (void)hipEventRecord(ev[0], st); (void)hipEventRecord(ev[1], st); }
-    if (x && mt) launch_sweep_t<true, UAM_RNG_MT19937>(e, p, st);
-    else if (x) launch_sweep_t<true, UAM_RNG_PHILOX>(e, p, st);
-    else if (mt) launch_sweep_t<false, UAM_RNG_MT19937>(e, p, st);
-    else launch_sweep_t<false, UAM_RNG_PHILOX>(e, p, st);
+#if UAM_STAMP
+    {   /* development build: per-phase s_memtime of every wave of the step kernel: mean and max over waves */
+        UamParams ps = p;
+        const int nw = grid_of(e) * (e->T / 64 > 0 ? e->T / 64 : 1);
+        static unsigned long long* dbuf = nullptr; static int dcap = 0; static int printed = 0;
+        if (dcap < nw) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void**)&dbuf, (size_t)nw * UAM_NSTAMP * 8); dcap = nw; }
+        (void)hipMemsetAsync(dbuf, 0, (size_t)nw * UAM_NSTAMP * 8, st);
+        ps.actions_out = dbuf;
+        hipLaunchKernelGGL(e->step_kernel, dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), st, ps);
+        if ((printed++ % 16) == 8) {
+            std::vector<unsigned long long> h((size_t)nw * UAM_NSTAMP);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[UAM_NSTAMP] = {0}, mx[UAM_NSTAMP] = {0}, tmax = 0, tsum = 0;
+            for (int w = 0; w < nw; w++) {
+                double t = 0;
+                for (int i = 0; i < UAM_NSTAMP; i++) { const double v = (double)h[(size_t)w * UAM_NSTAMP + i]; sum[i] += v; if (v > mx[i]) mx[i] = v; t += v; }
+                tsum += t; if (t > tmax) tmax = t;
+            }
+            fprintf(stderr, "[stamp step] waves=%d mean:", nw);
+            for (int i = 0; i < 9; i++) fprintf(stderr, " %.0f", sum[i] / nw);
+            fprintf(stderr, " | total %.0f\n[stamp step]        max:", tsum / nw);
+            for (int i = 0; i < 9; i++) fprintf(stderr, " %.0f", mx[i]);
+            fprintf(stderr, " | total %.0f\n", tmax);
+        }
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(e->step_kernel, dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), st, p);
     if (sample) { (void)hipEventRecord(ev[2], st); e->ksamples++; }
 }
 

@@ -13,7 +13,8 @@ import uamenv  # noqa: E402
 B, N, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 variant = sys.argv[4] if len(sys.argv) > 4 else "continuous"
 launches = int(sys.argv[5]) if len(sys.argv) > 5 else 20
-env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=0)
+env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=0, rng=os.environ.get("PROBE_RNG", "philox"),
+                                      precision=os.environ.get("PROBE_PRECISION", "f32"))
 env.reset()
 dev = env.device
 am = env.cfg.action_mode

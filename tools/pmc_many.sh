@@ -17,9 +17,11 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/p*/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-40:]
+        k = r["Kernel_Name"][:70]
         if "uam_sweep" not in k: continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[k]["_dur_us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        acc[k]["_vgpr"].append(float(r["VGPR_Count"])); acc[k]["_lds"].append(float(r["LDS_Block_Size"])); acc[k]["_scratch"].append(float(r["Scratch_Size"]))
 for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):
