@@ -47,6 +47,7 @@ class UamConfig(C.Structure):
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
         ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
         ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("fuse_rollout", C.c_int32),
+        ("graph_safe", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -107,6 +108,7 @@ SYMBOLS = [
     ("uam_step", C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     ("uam_step_many", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     ("uam_rollout", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    ("uam_rollout_policy", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("uam_steps_per_launch", C.c_int32, [_P, C.c_int32]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),

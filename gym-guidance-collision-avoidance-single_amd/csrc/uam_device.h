@@ -133,6 +133,9 @@ struct UamParams {
     int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep, wall_term, knn, shaped;
     uint32_t seed_lo, seed_hi, gid0;
     uint32_t step_index;          /* uam_step calls so far: Philox counter of the step draws */
+    uint32_t* env_step;           /* graph-safe handles: [B] the same counter per env in device memory (NULL otherwise); the
+                                     kernels then read it from here and the step advances it, so no kernel argument changes
+                                     between calls */
     float W32, H32, vmax32, psig32;
     float sep2_32, nmac2_32, init2_32;   /* float32 squared-distance thresholds: min{v : sqrtf(v) >= thr} */
     float inv_W32, inv_H32, inv_vden32;  /* reciprocals for the normalised float32 obs */
@@ -153,6 +156,9 @@ struct UamParams {
     int32_t act_step_words;       /* act_step_words 32-bit words resp. B elements per step */
     int32_t mt_win;               /* MT19937 step kernel: capacity in words of the per-env stream window in LDS (<= 224) */
     int32_t mt_first;             /* words of it twisted ahead at the head of every step (a cooperative refill takes mt_win) */
+    int32_t many_policy;          /* uam_sweep_many_kernel: -1 = actions from the tape; 0 / 1 = the built-in policy of that kind is
+                                     evaluated inside the launch from the ownship state (policy_lo/hi/call as for uam_policy;
+                                     actions_out, if not NULL, receives the [K, B(,2)] actions taken) */
     int32_t obs_direct;           /* uam_sweep_many_kernel: 1 = rows leave straight from registers (no LDS staging) */
     int32_t obs_slots;            /* uam_sweep_many_kernel: 0 = only the last step emits the observation (into obs);
                                      R > 0 = step k emits its observation into slot k % R of obs[R][B][D] (uam_rollout) */
@@ -176,27 +182,37 @@ enum { UAM_PH_OWN_NOISE = 0, UAM_PH_SPAWN = 1, UAM_PH_RESET_SPAWN = 3, UAM_PH_RE
 #define UAM_TWO_PI 0x1.921fb54442d18p+2
 #define UAM_DEG2RAD (0x1.921fb54442d18p+1 / 180.0)
 
-/* ------------------------------------------------------------------ Philox4x32-10 */
-__device__ __forceinline__ void uam_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                           uint32_t k1, uint32_t* o)
+/* ------------------------------------------------------------------ Philox4x32-10
+ * WIDE: one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair — the integer multiplier
+ * is quarter rate on gfx950 and Philox is nothing but multiplies, but the 64-bit pairs cost registers (63 -> 71 VGPRs in
+ * the lean step kernel, which lives on the 8-waves/SIMD line), so only the instances with room use it: the
+ * RandIntruder heading-change draws (one block per quad per step).  Same function of its inputs either way. */
+template <bool WIDE>
+__device__ __forceinline__ void uam_philox_t(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                             uint32_t k1, uint32_t* o)
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-#if UAM_PHILOX_WIDE
-        /* one 32x32->64 multiply per product (v_mad_u64_u32) instead of a mul_hi + mul_lo pair */
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-#else
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-#endif
+        uint32_t hi0, lo0, hi1, lo1;
+        if constexpr (WIDE || UAM_PHILOX_WIDE) {
+            const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+            hi0 = (uint32_t)(p0 >> 32); lo0 = (uint32_t)p0;
+            hi1 = (uint32_t)(p1 >> 32); lo1 = (uint32_t)p1;
+        } else {
+            hi0 = __umulhi(0xD2511F53u, c0); lo0 = 0xD2511F53u * c0;
+            hi1 = __umulhi(0xCD9E8D57u, c2); lo1 = 0xCD9E8D57u * c2;
+        }
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ void uam_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t* o)
+{
+    uam_philox_t<false>(c0, c1, c2, c3, k0, k1, o);
 }
 
 __device__ __forceinline__ double uam_u53(uint32_t a, uint32_t b)
@@ -437,6 +453,10 @@ template <> struct Rng<UAM_RNG_PHILOX> {
     {
         uam_philox(gid, reset_phase ? c_reset : c_step, (purpose << 16) | idx, attempt, k0, k1, w);
     }
+    __device__ __forceinline__ void block_wide(bool reset_phase, uint32_t purpose, uint32_t idx, uint32_t attempt, uint32_t* w)
+    {
+        uam_philox_t<true>(gid, reset_phase ? c_reset : c_step, (purpose << 16) | idx, attempt, k0, k1, w);
+    }
     __device__ __forceinline__ void quad(bool reset_phase, uint32_t purpose, uint32_t idx, double* u)
     {
         uint32_t w[4];
@@ -504,6 +524,13 @@ __device__ __forceinline__ void uam_philox_normals(uint32_t gid, uint32_t c_step
     uam_sincos(UAM_TWO_PI * u2, &sn, &cs);
     zh = r * cs;
     zs = r * sn;
+}
+
+/* Philox step counter of env `env` for step k of this launch: the kernel argument, or (graph-safe handles) the env's
+ * own counter in device memory — the same number, since every env takes every step */
+__device__ __forceinline__ uint32_t uam_step_of(const UamParams& p, int env, int k)
+{
+    return p.env_step ? p.env_step[env] : p.step_index + (uint32_t)k;
 }
 
 /* ------------------------------------------------------------------ small helpers */
@@ -792,15 +819,17 @@ __device__ __forceinline__ void quad_store_pos(const UamParams& p, size_t base, 
     }
 }
 
+/* with_speed = false: only headings changed (a RandIntruder heading change keeps the speed, :332-336), so the held
+ * speeds are not rewritten — a third less write-back for the ~34 % of quads in which an intruder changed heading */
 template <bool POS64, bool SH>
-__device__ __forceinline__ void quad_store_vel(const UamParams& p, size_t base, const Quad<POS64, SH>& q)
+__device__ __forceinline__ void quad_store_vel(const UamParams& p, size_t base, const Quad<POS64, SH>& q, bool with_speed = true)
 {
     *(float4*)(p.s.vx + base) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
     *(float4*)(p.s.vy + base) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
     if (SH) {
         double2* as = (double2*)(p.s.isp + base);
         double2* ah = (double2*)(p.s.ihd + base);
-        as[0] = make_double2(q.sp[0], q.sp[1]); as[1] = make_double2(q.sp[SH ? 2 : 0], q.sp[SH ? 3 : 0]);
+        if (with_speed) { as[0] = make_double2(q.sp[0], q.sp[1]); as[1] = make_double2(q.sp[SH ? 2 : 0], q.sp[SH ? 3 : 0]); }
         ah[0] = make_double2(q.hd[0], q.hd[1]); ah[1] = make_double2(q.hd[SH ? 2 : 0], q.hd[SH ? 3 : 0]);
     }
 }
@@ -1103,6 +1132,38 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     rox = oxf; roy = oyf;
 }
 
+/* ------------------------------------------------------------------ built-in device-side policies
+ * Functions of the ownship / goal state only, so the looped kernel's ownship wave can evaluate them itself and close
+ * the loop inside a launch (uam_rollout_policy); uam_policy_kernel evaluates the same function from HBM state.
+ *   kind 0: uniform random action from Philox(policy seed; env, call number)
+ *   kind 1: goal seeking — turn toward the goal, full throttle
+ * Returns the action as the one or two 32-bit words of the handle's action layout. */
+__device__ __forceinline__ void uam_policy_eval(const UamParams& p, const int kind, const int e, const float ox, const float oy,
+                                                const double hd, const double gx, const double gy, const uint32_t call,
+                                                uint32_t& w0, uint32_t& w1)
+{
+    int a0 = 1, a1 = 1;
+    float ac = 0.f;
+    if (kind == 0) {
+        uint32_t w[4];
+        uam_philox(p.gid0 + (uint32_t)e, call, (UAM_PH_POLICY << 16), 0, p.policy_lo, p.policy_hi, w);
+        a0 = (int)(w[0] % 3u);
+        a1 = (int)(w[1] % 3u);
+        ac = (float)(2.0 * uam_u53(w[2], w[3]) - 1.0);
+    } else {
+        const double bearing = atan2(gy - (double)oy, gx - (double)ox);
+        double diff = bearing - hd;
+        diff = diff - UAM_TWO_PI * floor((diff + 0.5 * UAM_TWO_PI) / UAM_TWO_PI);
+        a0 = diff > 0.5 * p.c->d_heading ? 2 : (diff < -0.5 * p.c->d_heading ? 0 : 1);
+        a1 = 2;
+        ac = (float)fmax(-1.0, fmin(1.0, 1.0 + diff / p.c->d_heading));
+    }
+    if (p.action_mode == UAM_ACT_DISCRETE9) { w0 = (uint32_t)(a0 * 3 + a1); w1 = w0; }
+    else if (p.action_mode == UAM_ACT_PAIR) { w0 = (uint32_t)a0; w1 = (uint32_t)a1; }
+    else if (p.action_mode == UAM_ACT_DISCRETE3) { w0 = (uint32_t)a0; w1 = w0; }
+    else { w0 = __float_as_uint(ac); w1 = w0; }
+}
+
 /* ------------------------------------------------------------------ ownship phase
  * Ownship.step (:299-309; 2Env :294-304) + the env-level tail of _terminal_reward (:179-185), one thread per env.
  * The state lives in OwnRegs: the single-step kernel loads it, updates it and stores it back; the looped kernel
@@ -1157,6 +1218,33 @@ __device__ __forceinline__ void own_fetch_inputs(const UamParams& p, const int e
     if constexpr (RNG == UAM_RNG_PHILOX) {
         const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
         r.zh = z.x; r.zs = z.y;
+    }
+}
+
+/* out of line for the looped kernel: inlined, the policy's fp64 atan2 and Philox rounds put 26 more VGPRs on every lane
+ * of the kernel (108 -> 134, one wave per SIMD less) although only its ownship wave ever runs them */
+__device__ __attribute__((noinline)) uint2 uam_policy_eval_fn(const UamParams* p, int kind, int e, float ox, float oy, double hd,
+                                                              double gx, double gy, uint32_t call)
+{
+    uint32_t w0, w1;
+    uam_policy_eval(*p, kind, e, ox, oy, hd, gx, gy, call, w0, w1);
+    return make_uint2(w0, w1);
+}
+
+/* looped kernel: the inputs of step k for env e — noise from the buffer drawn ahead; the action from the tape, or from
+ * the built-in policy evaluated on the ownship registers as they are NOW (i.e. after the update of step k - 1).  The
+ * action taken is recorded in actions_out when the caller asked for it. */
+template <int RNG, bool POLICY = true>
+__device__ __forceinline__ void own_inputs(const UamParams& p, const int e, const int k, const OwnRegs& r, OwnIn& in)
+{
+    if (!POLICY || p.many_policy < 0) { own_fetch_inputs<RNG>(p, e, k, in); return; }
+    const double2 z = p.noise[(size_t)k * (size_t)p.B + e];
+    in.zh = z.x; in.zs = z.y;
+    const uint2 a = uam_policy_eval_fn(&p, p.many_policy, e, r.ox, r.oy, r.hd, r.gx, r.gy, p.policy_call + (uint32_t)k);
+    in.w0 = a.x; in.w1 = a.y;
+    if (p.actions_out) {
+        if (p.action_mode == UAM_ACT_PAIR) ((uint2*)p.actions_out)[(size_t)k * (size_t)p.B + e] = make_uint2(in.w0, in.w1);
+        else ((uint32_t*)p.actions_out)[(size_t)k * (size_t)p.B + e] = in.w0;
     }
 }
 
@@ -1470,7 +1558,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
      * the by-value copy: the hot path then does not have to keep (or spill) ~40 SGPRs for them */
     const UamParams& pk = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
     Rng<RNG> rng;
-    bool vel_dirty = false;
+    bool vel_dirty = false;      /* some velocity / heading of my quad changed: respawn, reset, heading change */
+    bool sp_dirty = false;       /* ... and a held speed with it: respawn or reset only */
     bool mt_used = false;
     if constexpr (RNG == UAM_RNG_MT19937) {
         /* the cursor as the ownship thread left it; every lane of the group draws the same words from here on */
@@ -1483,17 +1572,17 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
 
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
-        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
+        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = uam_step_of(pk, env, k); rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
             spawn_intruder<POS64, RNG, LEAN, KC>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
-            vel_dirty = true;
+            vel_dirty = true; sp_dirty = true;
         }
     } else if (env_ok) {
-        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         uint32_t pend = 0;                  /* my slots whose velocity is still to be computed */
@@ -1512,7 +1601,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
                 q.set((int)jj, X, Y, prom, 0.f, 0.f, sp, hd);
 #pragma unroll
                 for (int j = 0; j < 4; j++) if ((uint32_t)j == jj) { spv[j] = sp; hdv[j] = hd; }
-                vel_dirty = true;
+                vel_dirty = true; sp_dirty = true;
             }
         }
         /* the trig of the respawned slots after the last draw, each lane for its own slots only */
@@ -1559,12 +1648,12 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
-            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = p.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
             /* one Philox block per quad: word j is intruder j's Bernoulli uniform u; a change takes its second
              * uniform as u / hc_prob (uniform on [0,1) given u < hc_prob) */
             if (quad_ok) {
                 uint32_t w[4];
-                rng.block(false, UAM_PH_HEADCHG, (uint32_t)gl, 0, w);
+                rng.block_wide(false, UAM_PH_HEADCHG, (uint32_t)gl, 0, w);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (4u * gl + j < (uint32_t)p.N && (unsigned long long)w[j] < p.hc_thr) {
@@ -1648,9 +1737,9 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)k; rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
+        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = uam_step_of(pk, env, k); rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
         reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
-        vel_dirty = true;
+        vel_dirty = true; sp_dirty = true;
         if constexpr (PERSIST) {
             /* tell the env's ownship thread (in the block's ownship wave) to pick the new episode's state up:
              * every lane of the group has read its record by now (s0 above, the tail just before); the new state
@@ -1666,7 +1755,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         vel_dirty_acc = vel_dirty_acc || vel_dirty;
     } else if (quad_ok) {
         if (!(UAM_ABLATE & 16)) quad_store_pos<POS64, SH>(p, base, q);
-        if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q);
+        if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q, sp_dirty);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (obs_k && !(UAM_ABLATE & 2)) {
@@ -1691,6 +1780,10 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
                 obs_pack_wave<POS64, SH, PERSIST>(p, obs_k, stage, env_first, g - wave_first_g, gl, env_ok, quad_ok, q, tail);
             }
         }
+    }
+    if constexpr (!PERSIST) {
+        /* graph-safe handles: the env's step counter advances here, after every path that reads it */
+        if (p.env_step && env_ok && gl == 0) p.env_step[env] = p.env_step[env] + 1u;
     }
     UAM_STAMP_AT(8);
 #if UAM_STAMP
@@ -1742,7 +1835,9 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
  *    under a goal-seeking policy) before barrier B releases the sweepers.
  * Removes K - 1 launches and the dependent loads at the head of every step: small batches (4096 x 8, 8192 x 32 per
  * GPU of a sharded 65536 batch, 8192 x 64) are launch- and latency-bound, not HBM-bound. */
-/* OWNW = the block has the ownship wave (latency regime: one or two waves per SIMD, the fp64 chain is hidden).
+/* (The in-launch policies of uam_rollout_policy exist in the ownship-wave flavour only: the other one is held at 128
+ * VGPRs and already spills.)
+ * OWNW = the block has the ownship wave (latency regime: one or two waves per SIMD, the fp64 chain is hidden).
  * !OWNW = a shard that needs every wave slot of the chip for its sweeping waves (32768 x 32: 16 waves per CU) has
  * no room for ownship waves: threads tid < E of the sweeping waves run the ownship phase at the head of each step,
  * as in the single-step kernel, with their registers persistent too. */
@@ -1768,9 +1863,9 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         OwnIn cur, nxt;
         if (owns) {
             own_load(p, e, own);
-            own_fetch_inputs<RNG>(p, e, 0, cur);
+            own_inputs<RNG>(pk, e, 0, own, cur);
             own_update<true>(pk, *pk.c, own, cur, rec0 + 3 * lane);           /* step 0 */
-            if (K > 1) own_fetch_inputs<RNG>(p, e, 1, cur);
+            if (K > 1) own_inputs<RNG>(pk, e, 1, own, cur);
         }
         __syncthreads();
 #pragma unroll 1
@@ -1779,12 +1874,16 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
             float4* const rec_n = (k & 1) ? rec0 : rec1;
             if (owns && k + 1 < K) {
                 own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
-                if (k + 2 < K) own_fetch_inputs<RNG>(p, e, k + 2, nxt);
+                if (k + 2 < K) own_inputs<RNG>(pk, e, k + 2, own, nxt);
             }
             __syncthreads();                                                   /* A: sweep k done */
             if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
                 own_reload(p, e, own);                                         /* env was reset in step k */
-                if (k + 1 < K) own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
+                if (k + 1 < K) {
+                    if (p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 1, own, cur);   /* the policy sees the new episode */
+                    own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
+                    if (k + 2 < K && p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 2, own, nxt);
+                }
             }
             cur = nxt;
             __syncthreads();                                                   /* B: record k+1 final */
@@ -1808,7 +1907,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
     OwnIn oin;
     if (owns) {
         own_load(p, own_e, own);
-        own_fetch_inputs<RNG>(p, own_e, 0, oin);
+        own_inputs<RNG, OWNW>(pko, own_e, 0, own, oin);
     }
 #if UAM_STAMP
     unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1831,7 +1930,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         if constexpr (!OWNW) {
             if (owns) {
                 own_update<true>(pko, *pko.c, own, oin, rec0 + 3 * tid);
-                if (k + 1 < K) own_fetch_inputs<RNG>(pko, own_e, k + 1, oin);   /* in flight while this step sweeps */
+                if (k + 1 < K) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin);    /* in flight while this step sweeps */
             }
             __syncthreads();
         }
@@ -1848,7 +1947,10 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         if constexpr (OWNW) __syncthreads();                                   /* B */
 #endif
         if constexpr (!OWNW) {
-            if (owns && ((const uint32_t*)(rec0 + 3 * tid))[3] == 0xFFFFFFFFu) own_reload(p, own_e, own);   /* env was reset */
+            if (owns && ((const uint32_t*)(rec0 + 3 * tid))[3] == 0xFFFFFFFFu) {                             /* env was reset */
+                own_reload(p, own_e, own);
+                if (OWNW && k + 1 < K && p.many_policy >= 0) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin);
+            }
         }
     }
     if (owns) own_store(p, own_e, own);
@@ -1961,36 +2063,21 @@ __global__ void __launch_bounds__(256) uam_noise_kernel(const UamParams p, doubl
     const uint32_t k = (uint32_t)(t / (size_t)p.B);
     const uint32_t e = (uint32_t)(t - (size_t)k * p.B);
     double zh, zs;
-    uam_philox_normals(p.gid0 + e, base + k, p.seed_lo, p.seed_hi, zh, zs);
+    uam_philox_normals(p.gid0 + e, (p.env_step ? p.env_step[e] : base) + k, p.seed_lo, p.seed_hi, zh, zs);
     out[t] = make_double2(zh, zs);
 }
 
-/* built-in policies (bench / smoke utilities): thread per env */
+/* built-in policies as a launch of their own (uam_policy): thread per env, state from HBM */
 __global__ void uam_policy_kernel(const UamParams p)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.B) return;
-    int a0 = 1, a1 = 1;
-    float ac = 0.f;
-    if (p.policy_kind == 0) {
-        uint32_t w[4];
-        uam_philox(p.gid0 + (uint32_t)e, p.policy_call, (UAM_PH_POLICY << 16), 0, p.policy_lo, p.policy_hi, w);
-        a0 = (int)(w[0] % 3u);
-        a1 = (int)(w[1] % 3u);
-        ac = (float)(2.0 * uam_u53(w[2], w[3]) - 1.0);
-    } else {
-        /* goal seeking: turn toward the goal, full throttle */
-        const double bearing = atan2(p.s.goal_y[e] - (double)p.s.own_y[e], p.s.goal_x[e] - (double)p.s.own_x[e]);
-        double diff = bearing - p.s.own_h[e];
-        diff = diff - UAM_TWO_PI * floor((diff + 0.5 * UAM_TWO_PI) / UAM_TWO_PI);
-        a0 = diff > 0.5 * p.c->d_heading ? 2 : (diff < -0.5 * p.c->d_heading ? 0 : 1);
-        a1 = 2;
-        ac = (float)fmax(-1.0, fmin(1.0, 1.0 + diff / p.c->d_heading));
-    }
-    if (p.action_mode == UAM_ACT_DISCRETE9) ((int32_t*)p.actions_out)[e] = a0 * 3 + a1;
-    else if (p.action_mode == UAM_ACT_PAIR) ((int2*)p.actions_out)[e] = make_int2(a0, a1);
-    else if (p.action_mode == UAM_ACT_DISCRETE3) ((int32_t*)p.actions_out)[e] = a0;
-    else ((float*)p.actions_out)[e] = ac;
+    uint32_t w0, w1;
+    /* graph-safe handles: the call number comes from the env's step counter (one policy call per step) */
+    uam_policy_eval(p, p.policy_kind, e, p.s.own_x[e], p.s.own_y[e], p.s.own_h[e], p.s.goal_x[e], p.s.goal_y[e],
+                    p.env_step ? p.env_step[e] : p.policy_call, w0, w1);
+    if (p.action_mode == UAM_ACT_PAIR) ((uint2*)p.actions_out)[e] = make_uint2(w0, w1);
+    else ((uint32_t*)p.actions_out)[e] = w0;
 }
 
 /* ------------------------------------------------------------------ hindsight relabelling (stateless)

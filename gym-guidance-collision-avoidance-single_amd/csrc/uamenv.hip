@@ -47,7 +47,8 @@ struct uam_env {
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
     int Tm, Em;                 /* looped kernel: sweeping threads per block (+ 64 for its ownship wave), envs per block <= 64 */
-    uint32_t step_index;        /* uam_step calls so far */
+    uint32_t step_index;        /* uam_step calls so far (graph-safe handles: the device counters are the truth) */
+    uint32_t* env_step;         /* graph-safe handles: [B] per-env step counters in HBM */
     double2* noise;             /* [NOISE_AHEAD][B] ownship noise drawn ahead (Philox) */
     double2* noise_many;        /* [noise_many_cap][B] noise of one uam_step_many launch (grown on demand) */
     int noise_many_cap;
@@ -64,6 +65,7 @@ struct uam_env {
     bool timing;
     int64_t timed_launches;
     uint32_t policy_calls;
+    uint32_t* policy_row;       /* [2B] scratch action row of uam_rollout_policy's queued-launch form */
 };
 
 static UamSweepFn many_fn(const uam_env* e);
@@ -74,7 +76,7 @@ static UamSweepFn many4_fn(const uam_env* e);
 static inline size_t lds_many(const uam_env* e, int fl, bool staged);
 
 extern "C" const char* uam_last_error(void) { return g_err; }
-extern "C" const char* uam_version(void) { return "uamenv-hip 0.1 (gfx950, abi 1)"; }
+extern "C" const char* uam_version(void) { return "uamenv-hip 0.2 (gfx950, abi 2)"; }
 
 extern "C" int32_t uam_obs_dim(const uam_config* cfg)
 {
@@ -109,6 +111,7 @@ extern "C" int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
     c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
     c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->fuse_rollout = 0;
+    c->graph_safe = 0; c->reserved2 = 0;
     return UAM_OK;
 }
 
@@ -138,6 +141,7 @@ static int validate(const uam_config* c)
     if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
     if (c->precision < 0 || c->precision > UAM_POS_EXACT) return fail(UAM_EINVAL, "bad precision %d", c->precision);
     if (c->fuse_rollout < 0 || c->fuse_rollout > UAM_FUSE_NEVER) return fail(UAM_EINVAL, "bad fuse_rollout %d", c->fuse_rollout);
+    if (c->graph_safe && c->rng_mode != UAM_RNG_PHILOX) return fail(UAM_EINVAL, "graph_safe needs the Philox RNG");
     if (!(c->window_width > 0) || !(c->window_height > 0)) return fail(UAM_EINVAL, "window must be positive");
     if (!(c->max_speed > c->min_speed)) return fail(UAM_EINVAL, "max_speed must exceed min_speed");
     if (!(c->initial_min_dist >= 0) || c->initial_min_dist * 2 >= fmin(c->window_width, c->window_height))
@@ -241,6 +245,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->seed_lo = (uint32_t)c.seed; p->seed_hi = (uint32_t)(c.seed >> 32);
     p->gid0 = (uint32_t)(uint64_t)c.env_id_offset;
     p->step_index = e->step_index;
+    p->env_step = e->env_step;
     p->W32 = (float)c.window_width; p->H32 = (float)c.window_height;
     p->vmax32 = (float)c.max_speed; p->psig32 = (float)c.position_sigma;
     /* NEP-50: a float32 distance compares against float32(threshold) */
@@ -252,6 +257,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->spawn_sx = (float)c.window_width * 0x1p-24f; p->spawn_sy = (float)c.window_height * 0x1p-24f;
     p->min_speed32 = (float)c.min_speed; p->vrange32 = (float)(c.max_speed - c.min_speed);
     p->mt_win = e->mt_win; p->mt_first = e->mt_first;
+    p->many_policy = -1;
 }
 
 static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
@@ -282,6 +288,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->timing = false;
     e->timed_launches = 0;
     e->policy_calls = 0;
+    e->policy_row = nullptr;
     e->step_index = 0;
     e->ktiming = false;
     e->ksamples = 0;
@@ -372,6 +379,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
         if (hipMemcpy(e->cold, &e->hcold, sizeof(e->hcold), hipMemcpyHostToDevice) != hipSuccess) rc = fail(UAM_EIO, "hipMemcpy(cold config) failed");
     }
     if (cfg->rng_mode == UAM_RNG_PHILOX && !rc) rc = dev_alloc(e, &e->noise, (size_t)B * NOISE_AHEAD);
+    e->env_step = nullptr;
+    if (cfg->graph_safe && !rc) rc = dev_alloc(e, &e->env_step, (size_t)B);      /* zeroed */
     if (cfg->rng_mode == UAM_RNG_MT19937) {
         if (!rc) rc = dev_alloc(e, &e->s.mt_key, (size_t)B * UAM_MT_N);
         if (!rc) rc = dev_alloc(e, &e->s.mt_pos, (size_t)B);
@@ -463,6 +472,7 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
         e->cfg.seed = seeds[0];
     }
     HIP_TRY(hipMemset(e->s.reset_count, 0, (size_t)B * 4));
+    if (e->env_step) HIP_TRY(hipMemset(e->env_step, 0, (size_t)B * 4));
     e->step_index = 0;
     e->noise_valid = false;
     return UAM_OK;
@@ -560,7 +570,7 @@ static inline size_t lds_many(const uam_env* e, int fl, bool staged)
  * the sweeping waves */
 static int many_flavour(const uam_env* e)
 {
-    if (!many_instance_exists(e) || e->ktiming) return 0;
+    if (!many_instance_exists(e) || e->ktiming || e->env_step) return 0;
     if (const char* f = getenv("UAMENV_MANY")) {       /* development override: off / force / force4 */
         if (!strcmp(f, "off")) return 0;
         if (!strcmp(f, "force")) return 1;
@@ -695,7 +705,14 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
     int rc = check_obs_ptr(e, obs_out, &p);
     if (rc) return rc;
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
-    if (e->cfg.rng_mode == UAM_RNG_PHILOX) {
+    if (e->env_step) {
+        /* graph-safe: the noise of THIS step, keyed by the per-env counters in device memory; nothing in either
+         * launch's arguments depends on how many steps have run */
+        hipLaunchKernelGGL(uam_noise_kernel, dim3((unsigned)((e->cfg.num_envs + 255) / 256)), dim3(256), 0, st, p, e->noise, 0u, 1);
+        HIP_TRY(hipGetLastError());
+        p.noise = e->noise;
+        p.step_index = 0;
+    } else if (e->cfg.rng_mode == UAM_RNG_PHILOX) {
         /* ownship noise of the next NOISE_AHEAD steps in one lane-parallel launch (counter-based: the same
          * values the step would draw itself), off the step kernel's critical path */
         if (!e->noise_valid || e->step_index < e->noise_base || e->step_index - e->noise_base >= (uint32_t)NOISE_AHEAD) {
@@ -737,11 +754,18 @@ extern "C" int uam_step(uam_env* e, const void* actions, float* obs_out, float* 
 
 /* K steps from an action tape.  obs_slots = 0: obs_out (may be NULL) receives the observation after the last step;
  * obs_slots = R > 0: step k writes its observation into slot k % R of obs_out[R][B][D]. */
+/* policy_kind < 0: actions from `action_tape`.  Otherwise the built-in policy of that kind supplies a fresh action before
+ * every step from the state the previous step left (closed loop); `action_tape` is then the OUTPUT [K, B(,2)] that
+ * receives the actions taken (may be NULL when the chunk runs as one looped launch). */
 static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float* obs_out, int32_t obs_slots,
-                          float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream)
+                          float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream,
+                          int32_t policy_kind = -1, uint64_t policy_seed = 0)
 {
-    int rc = check_step_args(e, action_tape, reward_out, done_out);
+    int rc;
+    if (policy_kind < 0) rc = check_step_args(e, action_tape, reward_out, done_out);
+    else rc = check_step_args(e, action_tape ? action_tape : (const void*)reward_out, reward_out, done_out);
     if (rc) return rc;
+    if (policy_kind > 1) return fail(UAM_EINVAL, "unknown policy kind %d", policy_kind);
     if (K < 1) return fail(UAM_EINVAL, "K must be >= 1 (got %d)", K);
     if (obs_slots < 0) return fail(UAM_EINVAL, "obs_slots must be >= 0 (got %d)", obs_slots);
     if (obs_slots > 0 && !obs_out) return fail(UAM_EINVAL, "obs_slots > 0 needs obs_out");
@@ -753,7 +777,7 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
         /* slots after the first would lose the 16-byte alignment the staged obs path was chosen for */
         return fail(UAM_EINVAL, "obs slot size B*D*4 = %zu bytes is not a multiple of 16", slot_elems * 4);
     }
-    if (K > 1 && many_supported(e)) {
+    if (K > 1 && many_supported(e) && !(policy_kind >= 0 && many_flavour(e) != 1)) {
         /* one launch for all K steps (uam_sweep_many_kernel); the noise of exactly these steps is drawn first */
         hipStream_t st = (hipStream_t)stream;
         if (e->noise_many_cap < K) {
@@ -784,13 +808,34 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
         p.many_K = K;
         p.obs_slots = obs_slots;
         p.act_step_words = (int32_t)(B * abytes / 4);
+        if (policy_kind >= 0) {
+            p.many_policy = policy_kind;
+            p.policy_lo = (uint32_t)policy_seed; p.policy_hi = (uint32_t)(policy_seed >> 32);
+            p.policy_call = e->policy_calls;
+            p.actions_out = const_cast<void*>(action_tape);
+            e->policy_calls += (uint32_t)K;
+        }
         launch_many(e, p, st);
         HIP_TRY(hipGetLastError());
         e->step_index += (uint32_t)K;
         if (e->timing) e->timed_launches++;
         return UAM_OK;
     }
+    if (policy_kind >= 0 && !action_tape) {
+        /* queued launches need somewhere to put each step's actions: one [B] row owned by the handle */
+        if (!e->policy_row) { rc = dev_alloc(e, &e->policy_row, B * 2); if (rc) return rc; HIP_TRY(hipDeviceSynchronize()); }
+    }
     for (int k = 0; k < K; k++) {
+        if (policy_kind >= 0) {
+            void* row = action_tape ? (void*)((char*)const_cast<void*>(action_tape) + (size_t)k * B * abytes) : (void*)e->policy_row;
+            rc = uam_policy(e, policy_kind, policy_seed, row, stream);
+            if (rc) return rc;
+            rc = step_once(e, row, obs_slots > 0 ? obs_out + (size_t)(k % obs_slots) * slot_elems : (k == K - 1 ? obs_out : nullptr),
+                           reward_out + (size_t)k * B, done_out + (size_t)k * B, info_out ? info_out + (size_t)k * B : nullptr,
+                           (hipStream_t)stream);
+            if (rc) return rc;
+            continue;
+        }
         const void* a = (const char*)action_tape + (size_t)k * B * abytes;
         float* ob = obs_slots > 0 ? obs_out + (size_t)(k % obs_slots) * slot_elems : (k == K - 1 ? obs_out : nullptr);
         rc = step_once(e, a, ob, reward_out + (size_t)k * B, done_out + (size_t)k * B,
@@ -810,6 +855,17 @@ extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, flo
                              uint8_t* done_out, uint8_t* info_out, void* stream)
 {
     return step_many_impl(e, K, action_tape, obs_out, 0, reward_out, done_out, info_out, stream);
+}
+
+extern "C" int uam_policy(uam_env* e, int32_t kind, uint64_t policy_seed, void* actions_out, void* stream);
+
+extern "C" int uam_rollout_policy(uam_env* e, int32_t K, int32_t kind, uint64_t policy_seed, float* obs_slots_out,
+                                  int32_t obs_slots, float* reward_out, uint8_t* done_out, uint8_t* info_out,
+                                  void* actions_out, void* stream)
+{
+    if (kind < 0 || kind > 1) return fail(UAM_EINVAL, "unknown policy kind %d", kind);
+    if (obs_slots < 1) return fail(UAM_EINVAL, "uam_rollout_policy needs obs_slots >= 1 (got %d)", obs_slots);
+    return step_many_impl(e, K, actions_out, obs_slots_out, obs_slots, reward_out, done_out, info_out, stream, kind, policy_seed);
 }
 
 extern "C" int uam_rollout(uam_env* e, int32_t K, const void* action_tape, float* obs_slots_out, int32_t obs_slots,
@@ -1102,6 +1158,12 @@ extern "C" int uam_get_state(uam_env* e, uam_state_view* v)
     GET_ENV(own_vx, own_vx); GET_ENV(own_vy, own_vy); GET_ENV(goal_x, goal_x); GET_ENV(goal_y, goal_y);
     GET_ENV(no_conflict, no_conflict); GET_ENV(reset_count, reset_count);
     v->step_index = e->step_index;
+    if (e->env_step) {      /* graph replays advance the device counters without passing through the host */
+        uint32_t s0 = 0;
+        HIP_TRY(hipMemcpy(&s0, e->env_step, 4, hipMemcpyDeviceToHost));
+        v->step_index = s0;
+        e->step_index = s0;
+    }
 #undef GET_ENV
     if (e->cfg.rng_mode == UAM_RNG_MT19937) {
         if (v->mt_key || v->mt_pos) {
@@ -1208,7 +1270,13 @@ extern "C" int uam_set_state(uam_env* e, const uam_state_view* v)
     SET_ENV(own_x, own_x); SET_ENV(own_y, own_y); SET_ENV(own_heading, own_h); SET_ENV(own_speed, own_s);
     SET_ENV(own_vx, own_vx); SET_ENV(own_vy, own_vy); SET_ENV(goal_x, goal_x); SET_ENV(goal_y, goal_y);
     SET_ENV(no_conflict, no_conflict); SET_ENV(reset_count, reset_count);
-    if (v->step_index != UINT64_MAX) { e->step_index = (uint32_t)v->step_index; e->noise_valid = false; }
+    if (v->step_index != UINT64_MAX) {
+        e->step_index = (uint32_t)v->step_index; e->noise_valid = false;
+        if (e->env_step) {
+            std::vector<uint32_t> cs((size_t)B, (uint32_t)v->step_index);
+            HIP_TRY(hipMemcpy(e->env_step, cs.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        }
+    }
 #undef SET_ENV
     if (e->cfg.rng_mode == UAM_RNG_MT19937) {
         if (v->mt_key || v->mt_pos) {

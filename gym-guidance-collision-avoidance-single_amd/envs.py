@@ -331,6 +331,30 @@ class BatchedSingleAircraftEnv:
         self._keep = action_tape
         return obs_out
 
+    def rollout_policy(self, K, kind="goal", seed=1, rew_out=None, done_out=None, info_out=None, obs_out=None, actions_out=None):
+        """K closed-loop steps with a built-in device-side policy ('random' | 'goal') choosing a fresh action before
+        every step (uam_rollout_policy).  Returns (obs_out [R,B,D], rewards [K,B], dones [K,B] uint8, infos [K,B],
+        actions [K,B(,2)])."""
+        torch = self._torch
+        K = int(K)
+        B, dev = self.num_envs, self.device
+        am = self.cfg.action_mode
+        if rew_out is None:
+            rew_out = torch.empty((K, B), dtype=torch.float32, device=dev)
+        if done_out is None:
+            done_out = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        if info_out is None:
+            info_out = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        if actions_out is None:
+            actions_out = torch.empty((K, B, 2) if am == capi.ACT_PAIR else (K, B),
+                                      dtype=torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32, device=dev)
+        if obs_out is None:
+            obs_out = self._obs.view(1, B, self.obs_dim)
+        capi.check(self._lib.uam_rollout_policy(self._h, K, {"random": 0, "goal": 1}[kind], int(seed), obs_out.data_ptr(),
+                                                int(obs_out.shape[0]), rew_out.data_ptr(), done_out.data_ptr(),
+                                                info_out.data_ptr(), actions_out.data_ptr(), self._stream()))
+        return obs_out, rew_out, done_out, info_out, actions_out
+
     def steps_per_launch(self, K):
         """K if a chunk of K steps runs as one launch of the looped kernel on this handle, else 1."""
         return int(self._lib.uam_steps_per_launch(self._h, int(K)))
@@ -427,6 +451,60 @@ class BatchedSingleAircraftEnv:
             arrs[n] = np.ascontiguousarray(a, dtype=dt)
         v = capi.make_view(arrs, B, N)
         capi.check(self._lib.uam_set_state(self._h, C.byref(v)))
+
+
+class GraphedLoop:
+    """A closed acting loop captured ONCE into a HIP graph and replayed: `policy(obs) -> actions` followed by
+    `env.step`, `steps` times per replay, with no host round trip between policy and env or between steps — the loop
+    of baselines/ppo2/runner.py:26-38 / Algorithms/MCTS/Agent_RandInt.py:36-46 for batches small enough to be
+    launch-bound.  Needs an env built with `graph_safe=True` (the step counter of the random draws then lives in
+    device memory, so the captured kernels' arguments stay valid for every replay).
+
+    `policy` must be capturable: device-side torch ops on the static observation buffer, or `env.policy_actions(kind,
+    out=...)`; it returns a device tensor in the env's action layout.  After `replay()` the results of the last
+    `steps` steps are in `rewards[steps, B]`, `dones[steps, B]` (uint8), `infos[steps, B]` (codes) and `obs` (after
+    the last step) — static buffers that the next replay overwrites."""
+
+    def __init__(self, env, policy, steps=1):
+        torch = env._torch
+        if not int(env.cfg.graph_safe):
+            raise ValueError("GraphedLoop needs an env created with graph_safe=True")
+        self.env, self.steps = env, int(steps)
+        B, dev = env.num_envs, env.device
+        self.rewards = torch.zeros((self.steps, B), dtype=torch.float32, device=dev)
+        self.dones = torch.zeros((self.steps, B), dtype=torch.uint8, device=dev)
+        self.infos = torch.zeros((self.steps, B), dtype=torch.uint8, device=dev)
+        self.obs = env._obs
+        self._policy = policy
+        # torch's capture protocol: one eager run on a side stream first (lazy initialisations happen there), with the
+        # env state put back afterwards so that the capture itself does not advance the episode
+        st = env.get_state()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        env.set_state(st)
+        env.observe()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        torch.cuda.synchronize(dev)
+        env.set_state(st)           # a capture only records: nothing ran, but keep the contract obvious
+        env.observe()
+
+    def _body(self):
+        env = self.env
+        for j in range(self.steps):
+            a = self._policy(self.obs)
+            capi.check(env._lib.uam_step(env._h, a.data_ptr(), self.obs.data_ptr(), self.rewards[j].data_ptr(),
+                                         self.dones[j].data_ptr(), self.infos[j].data_ptr(), env._stream()))
+            self._keep = a
+
+    def replay(self):
+        self.graph.replay()
+        return self.obs, self.rewards, self.dones, self.infos
 
 
 class SingleAircraftEnv:

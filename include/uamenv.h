@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define UAM_ABI_VERSION 1
+#define UAM_ABI_VERSION 2
 
 /* ---- error codes (negative errno values) ---- */
 #define UAM_OK        0
@@ -140,6 +140,14 @@ typedef struct uam_config {
                                   K queued single-step launches otherwise; UAM_FUSE_ALWAYS (1) uses the looped kernel
                                   whenever the handle's modes have one (float32 + Philox), in as many rounds as the grid
                                   needs; UAM_FUSE_NEVER (2).  Results are identical in every case. */
+    int32_t graph_safe;        /* 1: uam_step / uam_policy / uam_observe only enqueue kernels whose arguments never change
+                                  from one call to the next — the step counter of the Philox draws lives in device memory
+                                  (one counter per env, advanced by the step itself) and the ownship noise is drawn by a
+                                  one-step launch in front of every step — so a caller can capture policy + step into a
+                                  HIP graph ONCE and replay it: the closed loop of baselines/ppo2/runner.py:26-38 or
+                                  Algorithms/MCTS/Agent_RandInt.py:36-46 without a host round trip per step.  Results are
+                                  bit-identical to graph_safe = 0.  Philox only. */
+    int32_t reserved2;
 } uam_config;
 
 enum { UAM_FUSE_AUTO = 0, UAM_FUSE_ALWAYS = 1, UAM_FUSE_NEVER = 2 };
@@ -222,6 +230,16 @@ int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_o
  * single-launch form for small batches. */
 int uam_rollout(uam_env* env, int32_t K, const void* action_tape, float* obs_slots_out, int32_t obs_slots,
                 float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
+
+/* uam_rollout as a CLOSED loop with one of the built-in device-side policies (see uam_policy): before every step the
+ * policy of `kind` picks a fresh action from the state the previous step left — the acting loop of
+ * Algorithms/MCTS/Agent.py:25-45 / baselines/ppo2/runner.py:26-38 with a scripted actor.  Small batches run all K
+ * steps as ONE launch of the looped kernel, whose ownship wave evaluates the policy on its registers (both built-in
+ * policies are functions of the ownship / goal state only); otherwise a policy launch and a step launch are queued
+ * per step.  Identical to K times (uam_policy, uam_step).  actions_out (device, may be NULL) receives the actions
+ * taken, [K, B] (or [K, B, 2]) in the handle's action layout. */
+int uam_rollout_policy(uam_env* env, int32_t K, int32_t kind, uint64_t policy_seed, float* obs_slots_out, int32_t obs_slots,
+                       float* reward_out, uint8_t* done_out, uint8_t* info_out, void* actions_out, void* stream);
 
 /* How uam_step_many / uam_rollout would run a chunk of K steps on this handle: K when all of them go into one
  * launch of the looped kernel, 1 when K single-step launches are queued (0 on a bad argument). */

@@ -41,6 +41,7 @@ class UamConfig(C.Structure):
         ("heading_change_prob", C.c_double), ("heading_change_max_deg", C.c_double),
         ("wall_penalty", C.c_double), ("diagonal", C.c_double), ("knn", C.c_int32), ("wall_terminates", C.c_int32),
         ("conflict_coeff", C.c_double), ("goal_margin", C.c_double), ("shaped_reward", C.c_int32), ("fuse_rollout", C.c_int32),
+        ("graph_safe", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 

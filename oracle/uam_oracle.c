@@ -917,7 +917,7 @@ int uam_config_default(uam_config* c, int32_t B, int32_t N)
     c->own_x0 = 50; c->own_y0 = 50; c->own_speed0 = c->min_speed; c->own_heading0 = M_PI / 4;
     c->heading_change_prob = 0.1; c->heading_change_max_deg = 10;
     c->wall_penalty = -5 / 10.0; c->diagonal = 800; c->knn = 4; c->wall_terminates = 0;
-    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->fuse_rollout = 0;
+    c->conflict_coeff = 0.00025; c->goal_margin = 0; c->shaped_reward = 0; c->fuse_rollout = 0; c->graph_safe = 0; c->reserved2 = 0;
     return 0;
 }
 #endif

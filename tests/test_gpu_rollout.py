@@ -102,3 +102,39 @@ def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
     s = d["strong"]
     assert s["scaling"] == "strong" and s["variant"] == "continuous" and s["envs_per_gpu"] == 4096 and s["envs_total"] == 8192
     assert s["value"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("variant,B,N,K,kind", [
+    ("discrete9", 4096, 8, 24, "goal"),         # looped kernel, the ownship wave evaluates the policy
+    ("continuous", 8192, 32, 16, "goal"),       # BASELINE config 4's shard
+    ("randintruder", 2048, 64, 10, "goal"),
+    ("discrete9", 1000, 32, 12, "random"),
+    ("mcts", 3000, 20, 9, "random"),            # pair actions
+    ("discrete9", 32768, 32, 6, "goal"),        # the flavour without ownship wave
+    ("discrete9", 65536, 32, 3, "goal"),        # not fused: a policy launch and a step launch per step
+])
+def test_rollout_policy_closes_the_loop_like_policy_plus_step(uamenv, variant, B, N, K, kind):
+    """uam_rollout_policy (a fresh action from the device-side policy before EVERY step, inside the launch where the
+    chunk is fused) must equal K x (uam_policy, uam_step) bit for bit — rewards, dones, infos, the actions taken, every
+    observation and the final state — including across episode ends (goal seeking finishes episodes)."""
+    import torch
+    a = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=77)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=77)
+    a.reset(); b.reset()
+    acts_b = None
+    dones = 0
+    for rep in range(3 if kind == "goal" and B <= 8192 else 2):
+        reps_K = K if rep < 2 else 200                     # a long chunk so that goal seeking ends episodes
+        obs = torch.full((reps_K, B, a.obs_dim), float("nan"), dtype=torch.float32, device=a.device)
+        o_, rew, done, info, acts = a.rollout_policy(reps_K, kind=kind, seed=5, obs_out=obs)
+        for k in range(reps_K):
+            acts_b = b.policy_actions(kind, seed=5, out=acts_b)
+            assert torch.equal(acts[k], acts_b), (rep, k)
+            o, r, d, i = b.step(acts_b)
+            assert torch.equal(rew[k], r) and torch.equal(done[k], d.view(torch.uint8)) and torch.equal(info[k], i.codes), (rep, k)
+            assert torch.equal(obs[k], o), (rep, k)
+            dones += int(d.sum().item())
+        pu.compare_states(a.get_state(), b.get_state(), "after policy rollout %d" % rep, hold_sh=variant == "randintruder")
+    if kind == "goal" and B <= 8192:
+        assert dones > 0, "no episode ended: the reset hand-over to the policy was not exercised"
+    a.close(); b.close()
