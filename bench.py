@@ -68,8 +68,9 @@ def parse_args(argv=None):
                     "per GPU, growing to 256 for smaller shards)")
     ap.add_argument("--obs-slots", type=int, default=1, help="observation slots of a chunk: 1 = one [B,D] buffer "
                     "overwritten every step, 2 = double buffer, 0 = the full [K,B,D] rollout slab")
-    ap.add_argument("--exchange", default="all_gather", choices=["all_gather", "gather", "none"],
-                    help="N>1: the per-chunk collective of the reward/done slab (gather = to rank 0 only)")
+    ap.add_argument("--exchange", default="gather", choices=["all_gather", "gather", "none"],
+                    help="N>1: the per-chunk collective of the reward/done slab: gather = to rank 0, the master that "
+                         "SubprocVecEnv.step_wait collects in (north_star's single RCCL gather); all_gather = every rank")
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -146,7 +146,15 @@ class LazyInfos:
 
 
 class BatchedSingleAircraftEnv:
-    """B envs stepped by one fused HIP kernel per `step`; VecEnv-shaped."""
+    """B envs stepped by one fused HIP kernel per `step`; VecEnv-shaped.
+
+    Buffer ownership (differs from the reference, which returns a fresh array per call): `reset`, `step`, `step_wait`,
+    `observe` and `step_many` return the env's OWN device tensors (`obs`, `rews`, `dones`) and a lazy view of its info
+    codes.  They are valid until the next call that steps or resets the env, which overwrites them in place — a
+    rollout that keeps step t's tensors must `.clone()` them, or use `rollout_into` / `bind_outputs` to have each
+    step written straight into its slot of a caller-owned slab.  `LazyInfos` reads the code buffer on first access:
+    materialise it (`list(infos)` / `infos.copy()`) before stepping again if it is needed later.  `UamVecEnv` (NumPy
+    facing) alternates two host buffers and has none of this."""
 
     def __init__(self, num_envs, num_intruders=None, variant="discrete9", rng="philox", precision="f32", seed=0,
                  auto_reset=True, device=None, env_id_offset=0, config=Config, cfg=None, monitor=False, **overrides):
@@ -236,9 +244,23 @@ class BatchedSingleAircraftEnv:
 
     # ---- VecEnv API
     def seed(self, seeds=None):
-        """Re-seed: one seed per env (array) or None for cfg.seed + global env index."""
-        arr = None if seeds is None else np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (self.num_envs,)))
-        capi.check(self._lib.uam_seed(self._h, None if arr is None else arr.ctypes.data))
+        """Re-seed.  MT19937 handles: one seed per env (scalar = the same for all; array [B]), each in [0, 2**32) like
+        `np.random.seed` (which raises beyond that); None = cfg.seed + global env index.  Philox handles have ONE key
+        for the whole batch (the env index is part of the counter), so only a scalar seed makes sense there."""
+        if seeds is None:
+            capi.check(self._lib.uam_seed(self._h, None))
+            return seeds
+        raw = np.asarray(seeds)
+        if raw.size == 0 or (raw.dtype.kind not in "ui") or (raw.dtype.kind == "i" and (raw < 0).any()):
+            raise ValueError("seeds must be non-negative integers")
+        if self.cfg.rng_mode == capi.RNG_MT19937:
+            if (raw.astype(np.uint64) >= np.uint64(1) << np.uint64(32)).any():
+                raise ValueError("Seed must be between 0 and 2**32 - 1")        # np.random.seed's own message
+        elif raw.size > 1 and len(np.unique(raw)) > 1:
+            raise ValueError("a Philox handle has one key for the whole batch: pass a scalar seed "
+                             "(per-env streams come from the env index in the counter)")
+        arr = np.ascontiguousarray(np.broadcast_to(raw.astype(np.uint64), (self.num_envs,)))
+        capi.check(self._lib.uam_seed(self._h, arr.ctypes.data))
         return seeds
 
     def reset(self, mask=None):

@@ -418,7 +418,20 @@ def test_seed_array_and_reseed(uamenv, oracle):
     env.seed(np.array([3, 3, 3, 3], dtype=np.uint64))
     obs = env.reset().cpu().numpy()
     assert np.abs(obs[1] - fx["obs0"]).max() <= 1e-5
+    with pytest.raises(ValueError):          # np.random.seed raises beyond 32 bits; silently truncating would alias seeds
+        env.seed([1 << 32, 1, 2, 3])
+    with pytest.raises(ValueError):
+        env.seed([-1, 1, 2, 3])
     env.close()
+    ph = uamenv.BatchedSingleAircraftEnv(4, 8)
+    with pytest.raises(ValueError):          # one Philox key per batch: a per-env seed array would be silently ignored
+        ph.seed([1, 2, 3, 4])
+    ph.seed(9); a = ph.reset().clone()
+    ph.seed([9, 9, 9, 9]); b = ph.reset().clone()
+    ph.seed(10); c = ph.reset().clone()
+    import torch
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    ph.close()
 
 
 def test_monitor_episode_stats_match_oracle(uamenv, oracle):

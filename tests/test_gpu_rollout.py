@@ -98,7 +98,7 @@ def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
     assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["envs_total"] == 16384
     assert len(d["reps_ms"]) == 2 and d["ms_per_step"] > 0
     assert abs(d["value"] - 16384 * 70 / (d["ms_per_step"] * 70e-3)) / d["value"] < 1e-9
-    assert "all_gather" in d["config"]["exchange"] and "3 per rank" in d["config"]["exchange"]     # ceil(70 / 32)
+    assert "gather" in d["config"]["exchange"] and "3 per rank" in d["config"]["exchange"]     # ceil(70 / 32)
     s = d["strong"]
     assert s["scaling"] == "strong" and s["variant"] == "continuous" and s["envs_per_gpu"] == 4096 and s["envs_total"] == 8192
     assert s["value"] > 0 and "cpu_baseline" not in d
