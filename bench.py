@@ -213,14 +213,15 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
             torch.cuda.synchronize()
     run(warmup, 0)
     ex.drain()
-    reps_ms, span_ms, launches = [], [], []
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for r in range(reps):
+
+    def timed_region(nsteps, start):
+        """exactly `nsteps` steps bracketed by barrier + synchronize on both sides; max over ranks"""
         fence()
         state["launches"] = 0
         t0 = time.perf_counter()
         ev0.record()
-        run(steps, warmup + r * steps)
+        run(nsteps, start)
         ev1.record()
         ex.drain()
         fence()
@@ -229,9 +230,19 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        reps_ms.append(el * 1e3)
-        span_ms.append(ev0.elapsed_time(ev1))     # hipEvents on the launch stream around the region's launches
-        launches.append(state["launches"])
+        return el * 1e3, ev0.elapsed_time(ev1), state["launches"]      # hipEvents on the launch stream around the launches
+
+    reps_ms, span_ms, launches = [], [], []
+    for r in range(reps):
+        ms, sp, ln = timed_region(steps, warmup + r * steps)
+        reps_ms.append(ms); span_ms.append(sp); launches.append(ln)
+    steady = None
+    if steps < 1024 and args.policy == "random":
+        # a short region (the driver times 20 steps) is mostly its fixed costs — the closing barrier, one exposed
+        # exchange, the launch ramp; the same protocol over a long region says what the path sustains
+        n_long = 2048
+        ms, _, _ = timed_region(n_long, warmup + reps * steps)
+        steady = {"steps": n_long, "ms_per_step": ms / n_long, "value": float(sum(counts)) * n_long / (ms * 1e-3)}
     out = {"scaling": scaling, "variant": variant, "envs_per_gpu": B, "envs_total": sum(counts), "chunk": K,
            "obs_slots": R, "reps_ms": reps_ms, "median_ms": median(reps_ms),
            "value": float(sum(counts)) * steps / (median(reps_ms) * 1e-3),
@@ -242,7 +253,8 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
            "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives,
            # algorithmic bytes of one launch: a step's bytes for the step kernel; for the looped kernel (state in
            # registers for the whole launch) the state once + K x the step's outputs and inputs
-           "launch_bytes": env.rollout_bytes(K) if looped else env.step_bytes, "fuse": fuse}
+           "launch_bytes": env.rollout_bytes(max(1, int(round(steps / launches[0])))) if looped and launches[0] else env.step_bytes,
+           "fuse": fuse, "steady_state": steady}
     if want_bracketed and not looped and args.policy == "random":
         # per-launch durations: a separate pass with hipEvents around each launch (serialises the queue slightly)
         env.kernel_timing(True)
@@ -398,6 +410,7 @@ def main():
                                    "one async %s of the [%d, B_local] reward+done slab per chunk, double-buffered "
                                    "(overlaps the next chunk); %d per rank in a timed region"
                                    % (args.exchange, res["chunk"], -(-args.steps // res["chunk"]))},
+            "steady_state": res["steady_state"],
             "reps_ms": res["reps_ms"], "timing": "median of %d repetitions of the %d-step region, each bracketed by "
                                                  "barrier + synchronize, max over ranks" % (len(res["reps_ms"]), args.steps),
             "pair_steps_per_sec": res["value"] * N,
@@ -415,7 +428,7 @@ def main():
         if sec is not None:
             out[secondary] = {k: sec[k] for k in ("scaling", "variant", "envs_per_gpu", "envs_total", "chunk", "value",
                                                   "ms_per_step", "reps_ms", "kernel", "steps_per_launch",
-                                                  "stream_span_ms_per_step")}
+                                                  "stream_span_ms_per_step", "steady_state")}
             out[secondary]["workload"] = workloads[secondary]
             sms = sec["stream_span_ms_per_step"] * max(1.0, sec["steps_per_launch"])
             out[secondary]["launch_bytes"] = sec["launch_bytes"]

@@ -295,17 +295,18 @@ __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
  * their TEMPERED outputs in win[0 .. len): word k of a round depends on key[k], key[k+1] (both still in the previous
  * round's state while k >= gen) and key[(k+397) mod 624] (previous round's state for k < 227, else a word of this
  * round at least 227 places back), so any <= 227 consecutive words of one round are independent of each other.
- * Chunks of 4 L words: all of a chunk's loads are issued before its first store, so a lane pays one memory round trip
+ * Chunks of U L words: all of a chunk's loads are issued before its first store, so a lane pays one memory round trip
  * per chunk, not one per word (vmcnt is in-order: a load behind a store would wait for that store); a later chunk
  * never reads a word an earlier one wrote. */
 typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32W;
+template <int U = 4>
 __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, const int gen, const int len, const int gl,
                                               const int L, UAM_LDS_U32W win)
 {
-    for (int i0 = 0; i0 < len; i0 += 4 * L) {
-        uint32_t a[4], b[4], c[4];
+    for (int i0 = 0; i0 < len; i0 += U * L) {
+        uint32_t a[U], b[U], c[U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const int i = i0 + u * L + gl, k = pos + i;
             a[u] = 0; b[u] = 0; c[u] = 0;
             if (i < len) {
@@ -318,7 +319,7 @@ __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const int i = i0 + u * L + gl, k = pos + i;
             if (i < len) {
                 uint32_t v = a[u];
@@ -348,7 +349,7 @@ __device__ __attribute__((noinline)) MtRefillOut mt_refill_fn(uint32_t* key, int
     const int len = min(cap, UAM_MT_N - pos);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      /* earlier reads of the old window are done */
     __builtin_amdgcn_wave_barrier();
-    mt_twist_span(key, pos, gen, len, gl, L, win);
+    mt_twist_span<4>(key, pos, gen, len, gl, L, win);        /* (12 passes in flight = one round trip for 96 words, but +46 VGPRs: 2 waves/SIMD, slower overall) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -416,6 +417,25 @@ __device__ inline double mt_double(MtCtx& m)
 {
     uint32_t a = mt_u32(m) >> 5, b = mt_u32(m) >> 6;
     return ((double)a * 67108864.0 + (double)b) * 0x1p-53;
+}
+
+/* n (<= 4) consecutive rk_doubles when the window does not hold all their words: out of line, so that the ~30 call
+ * sites of a spawn's draws carry the inline window read plus ONE call instead of the whole refill / one-word machinery
+ * (the MT19937 kernels would not fit the instruction cache otherwise) */
+struct MtDrawOut { double u[4]; int pos, gen, win_base, win_len; };
+__device__ __attribute__((noinline)) MtDrawOut mt_draw_slow_fn(uint32_t* key, int pos, int gen, int win_base, int win_len, int cap,
+                                                               int gl, int L, UAM_LDS_U32 win, int n)
+{
+    MtCtx m;
+    m.key = key; m.pos = pos; m.gen = gen; m.has_gauss = 0; m.gauss = 0.0;
+    m.win = win; m.win_base = win_base; m.win_len = win_len; m.cap = cap; m.gl = gl; m.L = L;
+    MtDrawOut o;
+    o.u[0] = mt_double(m);
+    o.u[1] = mt_double(m);
+    o.u[2] = n > 2 ? mt_double(m) : 0.0;
+    o.u[3] = n > 2 ? mt_double(m) : 0.0;
+    o.pos = m.pos; o.gen = m.gen; o.win_base = m.win_base; o.win_len = m.win_len;
+    return o;
 }
 
 /* legacy_gauss (numpy/random/src/legacy/legacy-distributions.c) */
@@ -496,7 +516,9 @@ template <> struct Rng<UAM_RNG_MT19937> {
             u[0] = dbl(w[0], w[1]); u[1] = dbl(w[2], w[3]); u[2] = dbl(w[4], w[5]); u[3] = dbl(w[6], w[7]);
             return;
         }
-        u[0] = mt_double(m); u[1] = mt_double(m); u[2] = mt_double(m); u[3] = mt_double(m);
+        const MtDrawOut o = mt_draw_slow_fn(m.key, m.pos, m.gen, m.win_base, m.win_len, m.cap, m.gl, m.L, m.win, 4);
+        u[0] = o.u[0]; u[1] = o.u[1]; u[2] = o.u[2]; u[3] = o.u[3];
+        m.pos = o.pos; m.gen = o.gen; m.win_base = o.win_base; m.win_len = o.win_len;
     }
     __device__ __forceinline__ void two(bool, uint32_t, uint32_t, uint32_t, double& u1, double& u2)
     {
@@ -507,8 +529,9 @@ template <> struct Rng<UAM_RNG_MT19937> {
             u1 = dbl(a, b); u2 = dbl(c, d);
             return;
         }
-        u1 = mt_double(m);
-        u2 = mt_double(m);
+        const MtDrawOut o = mt_draw_slow_fn(m.key, m.pos, m.gen, m.win_base, m.win_len, m.cap, m.gl, m.L, m.win, 2);
+        u1 = o.u[0]; u2 = o.u[1];
+        m.pos = o.pos; m.gen = o.gen; m.win_base = o.win_base; m.win_len = o.win_len;
     }
 };
 
@@ -789,6 +812,7 @@ __device__ __forceinline__ void quad_load(const UamParams& p, size_t base, bool 
         q.x[0] = (P)a.x; q.x[1] = (P)a.y; q.x[2] = (P)a.z; q.x[3] = (P)a.w;
         q.y[0] = (P)b.x; q.y[1] = (P)b.y; q.y[2] = (P)b.z; q.y[3] = (P)b.w;
     }
+    /* (non-temporal LOADS of the state were tried: neutral at 65536 envs, 13 % slower at 1 M envs) */
     float4 c = *(const float4*)(p.s.vx + base);
     float4 d = *(const float4*)(p.s.vy + base);
     q.vx[0] = c.x; q.vx[1] = c.y; q.vx[2] = c.z; q.vx[3] = c.w;
@@ -1101,16 +1125,27 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     } else {
         /* the stream is sequential: every lane takes every intruder's draws; the owner of the slot keeps them and
          * does the fp64 trig for its own four slots afterwards (lane-parallel, 4 sincos per lane instead of N) */
+        /* quad by quad with the slot index a compile-time constant: the owner lane's assignments are plain
+         * predicated moves (a run-time slot index costs ~45 selects per intruder, and this loop is the serial
+         * critical path of the one wave in the launch that resets) */
         double spv[4] = {0.0, 0.0, 0.0, 0.0}, hdv[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < p.N; i++) {
-            typename PosT<POS64>::type X, Y; bool prom; double sp, hd;
-            spawn_draw<POS64, RNG>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, sp, hd);
-            if ((i >> 2) == gl) {
-                q.set(i & 3, X, Y, prom, 0.f, 0.f, sp, hd);
+        uint32_t promm = 0;
+        for (int c = 0; 4 * c < p.N; c++) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (j == (i & 3)) { spv[j] = sp; hdv[j] = hd; }
+            for (int j = 0; j < 4; j++) {
+                const int i = 4 * c + j;
+                if (i < p.N) {
+                    typename PosT<POS64>::type X, Y; bool prom; double sp, hd;
+                    spawn_draw<POS64, RNG>(p, rng, (uint32_t)i, true, oxf, oyf, X, Y, prom, sp, hd);
+                    if (c == gl) {
+                        q.x[j] = X; q.y[j] = Y; spv[j] = sp; hdv[j] = hd;
+                        if (SH) { q.sp[SH ? j : 0] = sp; q.hd[SH ? j : 0] = hd; }
+                        promm |= (prom ? 1u : 0u) << (4 + j);
+                    }
+                }
             }
         }
+        q.flags = promm;                   /* new objects: conflict flags cleared */
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (quad_ok && 4u * gl + j < (uint32_t)p.N) spawn_velocity<KC>(spv[j], hdv[j], q.vx[j], q.vy[j]);
