@@ -166,6 +166,8 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
         tape = torch.randint(0, 3, (TL, B, 2), dtype=torch.int32, device=dev, generator=gen)
     elif am == capi.ACT_DISCRETE3:
         tape = torch.randint(0, 3, (TL, B), dtype=torch.int32, device=dev, generator=gen)
+    elif am == capi.ACT_CONTINUOUS2:
+        tape = torch.rand((TL, B, 2), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
     else:
         tape = torch.rand((TL, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
     tape = torch.cat([tape, tape[:K]]).contiguous()       # any chunk of <= K rows is one contiguous slice

@@ -7,7 +7,7 @@ of the env interface (`envs.py`).
 """
 from . import _capi
 from ._capi import UamError, build, default_config
-from .envs import (BatchedSingleAircraftEnv, Config, GraphedLoop, LazyInfos, SingleAircraft2Env, SingleAircraftEnv,
+from .envs import (BatchedSingleAircraftEnv, Config, GraphedLoop, LazyInfos, PackagedConfig, PackagedSingleAircraft2Env, SingleAircraft2Env, SingleAircraftEnv,
                    SingleAircraftMCTSEnv, SingleAircraftMCTSRandIntruderEnv, SingleAircraftRandomEnv,
                    SingleAircraftDiscrete9HEREnv, SingleAircraftDiscrete3HEREnv, her_goal_reward,
                    her_input_reward, make_config)
@@ -17,7 +17,7 @@ from .mcts import BatchedMCTS, mcts_config
 from .vec_env import UamVecEnv, HostInfos
 
 __all__ = [
-    "GraphedLoop", "RolloutExchange",
+    "GraphedLoop", "RolloutExchange", "PackagedConfig", "PackagedSingleAircraft2Env",
     "BatchedSingleAircraftEnv", "Config", "LazyInfos", "SingleAircraft2Env", "SingleAircraftEnv",
     "SingleAircraftMCTSEnv", "SingleAircraftMCTSRandIntruderEnv", "SingleAircraftRandomEnv",
     "SingleAircraftDiscrete9HEREnv", "SingleAircraftDiscrete3HEREnv", "her_goal_reward", "her_input_reward",

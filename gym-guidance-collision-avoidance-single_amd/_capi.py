@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("UAMENV_LIB") or os.path.join(CSRC, "libuamenv_hip.so")   # UAMENV_LIB: development override
 
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
-ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3 = 0, 1, 2, 3
+ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3, ACT_CONTINUOUS2 = 0, 1, 2, 3, 4
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1

@@ -1178,13 +1178,15 @@ __device__ __forceinline__ void uam_policy_eval(const UamParams& p, const int ki
                                                 uint32_t& w0, uint32_t& w1)
 {
     int a0 = 1, a1 = 1;
-    float ac = 0.f;
+    float ac = 0.f, ac2 = 0.f, as2 = 1.f;      /* continuous2: un-offset heading command, speed command */
     if (kind == 0) {
         uint32_t w[4];
         uam_philox(p.gid0 + (uint32_t)e, call, (UAM_PH_POLICY << 16), 0, p.policy_lo, p.policy_hi, w);
         a0 = (int)(w[0] % 3u);
         a1 = (int)(w[1] % 3u);
         ac = (float)(2.0 * uam_u53(w[2], w[3]) - 1.0);
+        ac2 = ac;
+        as2 = (float)(2.0 * uam_u53(w[0], w[1]) - 1.0);
     } else {
         const double bearing = atan2(gy - (double)oy, gx - (double)ox);
         double diff = bearing - hd;
@@ -1192,7 +1194,9 @@ __device__ __forceinline__ void uam_policy_eval(const UamParams& p, const int ki
         a0 = diff > 0.5 * p.c->d_heading ? 2 : (diff < -0.5 * p.c->d_heading ? 0 : 1);
         a1 = 2;
         ac = (float)fmax(-1.0, fmin(1.0, 1.0 + diff / p.c->d_heading));
+        ac2 = (float)fmax(-1.0, fmin(1.0, diff / p.c->d_heading));
     }
+    if (p.action_mode == UAM_ACT_CONTINUOUS2) { w0 = __float_as_uint(ac2); w1 = __float_as_uint(as2); return; }
     if (p.action_mode == UAM_ACT_DISCRETE9) { w0 = (uint32_t)(a0 * 3 + a1); w1 = w0; }
     else if (p.action_mode == UAM_ACT_PAIR) { w0 = (uint32_t)a0; w1 = (uint32_t)a1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { w0 = (uint32_t)a0; w1 = w0; }
@@ -1246,7 +1250,7 @@ __device__ __forceinline__ void own_store(const UamParams& p, const int e, const
 template <int RNG>
 __device__ __forceinline__ void own_fetch_inputs(const UamParams& p, const int e, const int k, OwnIn& r)
 {
-    const bool is_pair = p.action_mode == UAM_ACT_PAIR;
+    const bool is_pair = p.action_mode == UAM_ACT_PAIR || p.action_mode == UAM_ACT_CONTINUOUS2;
     const uint32_t* __restrict__ aw = (const uint32_t*)p.actions;
     const size_t i0 = (is_pair ? 2 * (size_t)e : (size_t)e) + (size_t)k * (size_t)p.act_step_words;
     r.w0 = aw[i0]; r.w1 = aw[is_pair ? i0 + 1 : i0];
@@ -1278,7 +1282,7 @@ __device__ __forceinline__ void own_inputs(const UamParams& p, const int e, cons
     const uint2 a = uam_policy_eval_fn(&p, p.many_policy, e, r.ox, r.oy, r.hd, r.gx, r.gy, p.policy_call + (uint32_t)k);
     in.w0 = a.x; in.w1 = a.y;
     if (p.actions_out) {
-        if (p.action_mode == UAM_ACT_PAIR) ((uint2*)p.actions_out)[(size_t)k * (size_t)p.B + e] = make_uint2(in.w0, in.w1);
+        if (p.action_mode == UAM_ACT_PAIR || p.action_mode == UAM_ACT_CONTINUOUS2) ((uint2*)p.actions_out)[(size_t)k * (size_t)p.B + e] = make_uint2(in.w0, in.w1);
         else ((uint32_t*)p.actions_out)[(size_t)k * (size_t)p.B + e] = in.w0;
     }
 }
@@ -1294,6 +1298,11 @@ __device__ __forceinline__ void own_update(const UamParams& p, const UamCold& c,
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
+    else if (p.action_mode == UAM_ACT_CONTINUOUS2) {
+        /* heading += d_heading * a[0], speed += d_speed * a[1]: the un-offset form through the common (a - 1) update —
+         * (float32 + 1.0) - 1.0 is exact in float64 */
+        a0 = (double)af + 1.0; a1 = (double)__uint_as_float(in.w1) + 1.0;
+    }
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
     double hd = r.hd, sp = r.sp;
     hd += c.d_heading * (a0 - 1.0);
@@ -1351,7 +1360,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     const double gx = p.s.goal_x[e], gy = p.s.goal_y[e];
     /* branch-free action fetch: two 32-bit words whatever the encoding (the second aliases the first
      * unless the action is a pair), decoded after all loads are in flight */
-    const bool is_pair = p.action_mode == UAM_ACT_PAIR;
+    const bool is_pair = p.action_mode == UAM_ACT_PAIR || p.action_mode == UAM_ACT_CONTINUOUS2;
     const uint32_t* __restrict__ aw = (const uint32_t*)p.actions;
     const size_t i0 = (is_pair ? 2 * (size_t)e : (size_t)e) + (size_t)k * (size_t)p.act_step_words;
     const uint32_t w0 = aw[i0], w1 = aw[is_pair ? i0 + 1 : i0];
@@ -1374,6 +1383,7 @@ __device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
+    else if (p.action_mode == UAM_ACT_CONTINUOUS2) { a0 = (double)af + 1.0; a1 = (double)__uint_as_float(w1) + 1.0; }   /* see own_update */
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
     hd += c.d_heading * (a0 - 1.0);
     hd += 0.0 + c.heading_sigma * zh;
@@ -2111,7 +2121,7 @@ __global__ void uam_policy_kernel(const UamParams p)
     /* graph-safe handles: the call number comes from the env's step counter (one policy call per step) */
     uam_policy_eval(p, p.policy_kind, e, p.s.own_x[e], p.s.own_y[e], p.s.own_h[e], p.s.goal_x[e], p.s.goal_y[e],
                     p.env_step ? p.env_step[e] : p.policy_call, w0, w1);
-    if (p.action_mode == UAM_ACT_PAIR) ((uint2*)p.actions_out)[e] = make_uint2(w0, w1);
+    if (p.action_mode == UAM_ACT_PAIR || p.action_mode == UAM_ACT_CONTINUOUS2) ((uint2*)p.actions_out)[e] = make_uint2(w0, w1);
     else ((uint32_t*)p.actions_out)[e] = w0;
 }
 

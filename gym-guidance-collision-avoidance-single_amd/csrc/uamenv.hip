@@ -132,7 +132,7 @@ static int validate(const uam_config* c)
         if (!(c->diagonal > 0)) return fail(UAM_EINVAL, "diagonal must be positive");
         if (c->dynamics == UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "UAM_OBS_KNN5 is not defined for the RandIntruder dynamics");
     }
-    if (c->action_mode < 0 || c->action_mode > UAM_ACT_DISCRETE3) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
+    if (c->action_mode < 0 || c->action_mode > UAM_ACT_CONTINUOUS2) return fail(UAM_EINVAL, "bad action_mode %d", c->action_mode);
     if (!(c->goal_margin >= 0) || c->goal_margin * 2 >= fmin(c->window_width, c->window_height))
         return fail(UAM_EINVAL, "goal_margin %g leaves no room for the goal", c->goal_margin);
     if (c->shaped_reward && c->dynamics == UAM_DYN_RANDINTRUDER)
@@ -737,7 +737,7 @@ static int check_step_args(const uam_env* e, const void* actions, const float* r
     if (!e) return fail(UAM_EINVAL, "env is NULL");
     if (!actions) return fail(UAM_EINVAL, "actions is NULL");
     if (!reward_out || !done_out) return fail(UAM_EINVAL, "reward_out and done_out are required");
-    const uintptr_t am = e->cfg.action_mode == UAM_ACT_PAIR ? 7u : 3u;
+    const uintptr_t am = (e->cfg.action_mode == UAM_ACT_PAIR || e->cfg.action_mode == UAM_ACT_CONTINUOUS2) ? 7u : 3u;
     if ((uintptr_t)actions & am) return fail(UAM_EINVAL, "actions pointer is not aligned for action_mode %d", e->cfg.action_mode);
     if ((uintptr_t)reward_out & 3u) return fail(UAM_EINVAL, "reward_out must be 4-byte aligned");
     return UAM_OK;
@@ -771,7 +771,7 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
     if (obs_slots > 0 && !obs_out) return fail(UAM_EINVAL, "obs_slots > 0 needs obs_out");
     HIP_TRY(hipSetDevice(e->device));
     const size_t B = (size_t)e->cfg.num_envs;
-    const size_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    const size_t abytes = (e->cfg.action_mode == UAM_ACT_PAIR || e->cfg.action_mode == UAM_ACT_CONTINUOUS2) ? 8 : 4;
     const size_t slot_elems = B * (size_t)e->D;
     if (obs_slots > 0 && ((slot_elems * 4) & 15u) && e->D % 4 == 0 && (((uintptr_t)obs_out & 15u) == 0)) {
         /* slots after the first would lose the 16-byte alignment the staged obs path was chosen for */
@@ -1017,7 +1017,7 @@ extern "C" int64_t uam_rollout_bytes(const uam_env* e, int32_t K)
      * speed/heading read; per env the ownship/goal/flags/counter part of SURVEY's 150 B: 88 B), every step moves only
      * its outputs (observation row, reward, done, info) and inputs (action, 16 B of pre-drawn noise) */
     const int64_t N = e->cfg.num_intruders, B = e->cfg.num_envs;
-    const int64_t abytes = e->cfg.action_mode == UAM_ACT_PAIR ? 8 : 4;
+    const int64_t abytes = (e->cfg.action_mode == UAM_ACT_PAIR || e->cfg.action_mode == UAM_ACT_CONTINUOUS2) ? 8 : 4;
     const int64_t state = (24 + (e->hold_sh ? 16 : 0)) * N + 88;
     const int64_t io = 4 * (int64_t)e->D + 6 + abytes + 16;
     return B * (state + (int64_t)K * io);

@@ -57,10 +57,26 @@ class Config:
     n = 4
 
 
+class PackagedConfig(Config):
+    """The constants the packaged (deprecated) copy runs with: gym_guidance_collision_avoidance_single/envs/config.py
+    (heading_sigma 2 degrees, intruder_size 0 — pass num_intruders) and the literals of its
+    SingleAircraft2Env._terminal_reward (:155-176): NMAC -5, conflict -1, out of map -100 and terminal, goal +1."""
+    intruder_size = 0
+    heading_sigma = math.radians(2)
+    NMAC_penalty = -5
+    conflict_penalty = -1
+    wall_penalty = -100
+    goal_reward = 1
+    wall_terminates = True
+
+
 _VARIANTS = {
     # name: (obs_mode, action_mode, dynamics, random_own_start)
     "discrete9": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 0),    # Simulators/SingleAircraftEnv.py
     "continuous": (capi.OBS_NORM4, capi.ACT_CONTINUOUS1, capi.DYN_STRAIGHT, 0),  # Simulators/SingleAircraft2Env.py
+    # the packaged copy's action semantics (un-offset heading command, live speed command); its reward constants and
+    # out-of-map rule come with `config=PackagedConfig` (gym_guidance_collision_avoidance_single/envs/SingleAircraft2Env.py)
+    "continuous2": (capi.OBS_NORM4, capi.ACT_CONTINUOUS2, capi.DYN_STRAIGHT, 0),
     "mcts": (capi.OBS_RAW4, capi.ACT_PAIR, capi.DYN_STRAIGHT, 0),                # Simulators/SingleAircraftMCTSEnv.py
     "randintruder": (capi.OBS_RAW6, capi.ACT_PAIR, capi.DYN_RANDINTRUDER, 0),    # ...MCTSRandIntruderEnv.py
     "random_start": (capi.OBS_NORM4, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),  # Simulators/SingleAircraftRandomEnv.py
@@ -94,7 +110,7 @@ def make_config(num_envs, num_intruders=None, variant="discrete9", rng="philox",
         step_penalty=config.step_penalty, goal_reward=config.goal_reward,
         own_speed0=config.min_speed, wall_penalty=config.wall_penalty, diagonal=config.diagonal, knn=int(config.n),
         # the HER env ends the episode when the ownship leaves the map, but only under sparse_reward (:217-221)
-        wall_terminates=int(variant in ("her9", "her3") and bool(config.sparse_reward)),
+        wall_terminates=int((variant in ("her9", "her3") and bool(config.sparse_reward)) or bool(getattr(config, "wall_terminates", False))),
         conflict_coeff=config.conflict_coeff,
         # Discrete3HEREnv.py: goal 100 px inside the map (:349-353), reward shaped by the nearest intruder (:225-232)
         goal_margin=100.0 if variant == "her3" else 0.0, shaped_reward=int(variant == "her3"))
@@ -178,6 +194,8 @@ class BatchedSingleAircraftEnv:
         self.observation_space = spaces.Box(low=-1000, high=1000, shape=(nobs,), dtype=np.float32)
         if self.cfg.action_mode == capi.ACT_CONTINUOUS1:
             self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float64)
+        elif self.cfg.action_mode == capi.ACT_CONTINUOUS2:
+            self.action_space = spaces.Box(low=-1, high=1, shape=(2,), dtype=np.float64)
         else:
             self.action_space = spaces.Discrete(3 if self.cfg.action_mode == capi.ACT_DISCRETE3 else 9)
         self._h = C.c_void_p()
@@ -189,7 +207,7 @@ class BatchedSingleAircraftEnv:
             self._done = torch.empty((B,), dtype=torch.uint8, device=self.device)
             self._info = torch.empty((B,), dtype=torch.uint8, device=self.device)
         self._pending = None
-        self._act_numel = self.num_envs * (2 if self.cfg.action_mode == capi.ACT_PAIR else 1)
+        self._act_numel = self.num_envs * (2 if self.cfg.action_mode in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else 1)
         # fixed argument objects of the per-step call, built once
         self._step_fn = self._lib.uam_step
         self._fixed_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self._obs, self._rew, self._done, self._info))
@@ -218,14 +236,14 @@ class BatchedSingleAircraftEnv:
     def _as_actions(self, actions):
         torch = self._torch
         am = self.cfg.action_mode
-        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
         if isinstance(actions, torch.Tensor) and actions.dtype == dt and actions.device == self.device \
                 and actions.is_contiguous() and actions.numel() == self._act_numel:
             return actions          # fast path: a ready device tensor (the per-step host cost matters for small batches)
         if not isinstance(actions, torch.Tensor):
             actions = torch.as_tensor(np.asarray(actions), dtype=dt)
         a = actions.to(device=self.device, dtype=dt).contiguous()
-        want = self.num_envs * (2 if am == capi.ACT_PAIR else 1)
+        want = self.num_envs * (2 if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else 1)
         if a.numel() != want:
             raise ValueError("actions has %d elements, expected %d for %d envs" % (a.numel(), want, self.num_envs))
         return a
@@ -314,10 +332,10 @@ class BatchedSingleAircraftEnv:
         (obs after the last step, rewards [K,B], dones [K,B] uint8, info codes [K,B] uint8)."""
         torch = self._torch
         am = self.cfg.action_mode
-        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
         tape = torch.as_tensor(action_tape).to(device=self.device, dtype=dt).contiguous()
         K = int(tape.shape[0])
-        if tape.numel() != K * self.num_envs * (2 if am == capi.ACT_PAIR else 1):
+        if tape.numel() != K * self.num_envs * (2 if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else 1):
             raise ValueError("action tape has the wrong shape %s" % (tuple(tape.shape),))
         rew = torch.empty((K, self.num_envs), dtype=torch.float32, device=self.device)
         done = torch.empty((K, self.num_envs), dtype=torch.uint8, device=self.device)
@@ -333,7 +351,7 @@ class BatchedSingleAircraftEnv:
         rollout of baselines/ppo2/runner.py:26-38 with the actions already on the device.  Returns obs_out."""
         torch = self._torch
         am = self.cfg.action_mode
-        dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
         K = int(action_tape.shape[0])
         if action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous() \
                 or action_tape.numel() != K * self._act_numel:
@@ -368,8 +386,8 @@ class BatchedSingleAircraftEnv:
         if info_out is None:
             info_out = torch.empty((K, B), dtype=torch.uint8, device=dev)
         if actions_out is None:
-            actions_out = torch.empty((K, B, 2) if am == capi.ACT_PAIR else (K, B),
-                                      dtype=torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32, device=dev)
+            actions_out = torch.empty((K, B, 2) if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else (K, B),
+                                      dtype=torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32, device=dev)
         if obs_out is None:
             obs_out = self._obs.view(1, B, self.obs_dim)
         capi.check(self._lib.uam_rollout_policy(self._h, K, {"random": 0, "goal": 1}[kind], int(seed), obs_out.data_ptr(),
@@ -390,8 +408,8 @@ class BatchedSingleAircraftEnv:
         torch = self._torch
         am = self.cfg.action_mode
         if out is None:
-            shape = (self.num_envs, 2) if am == capi.ACT_PAIR else (self.num_envs,)
-            out = torch.empty(shape, dtype=torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32, device=self.device)
+            shape = (self.num_envs, 2) if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else (self.num_envs,)
+            out = torch.empty(shape, dtype=torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32, device=self.device)
         capi.check(self._lib.uam_policy(self._h, {"random": 0, "goal": 1}[kind], int(seed), out.data_ptr(), self._stream()))
         return out
 
@@ -560,8 +578,8 @@ class SingleAircraftEnv:
         # the action goes up through a page-locked word as well (a pageable torch.as_tensor(...).to(device) is a
         # synchronous copy of its own)
         am = v.cfg.action_mode
-        act_dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
-        act_shape = (1, 2) if am == capi.ACT_PAIR else (1,)
+        act_dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
+        act_shape = (1, 2) if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else (1,)
         self._h_act = torch.zeros(act_shape, dtype=act_dt, pin_memory=True)
         self._d_act = torch.zeros(act_shape, dtype=act_dt, device=v.device)
         self._h_side = torch.zeros((2,), dtype=torch.int32, pin_memory=True)   # no_conflict | nearest distance bits
@@ -626,6 +644,23 @@ class SingleAircraft2Env(SingleAircraftEnv):
         a = np.asarray(action, dtype=np.float64).reshape(-1)
         assert a.shape == (1,) and -1 <= a[0] <= 1, "given action is in incorrect shape"   # :127
         return np.asarray([a[0]], dtype=np.float32)
+
+
+class PackagedSingleAircraft2Env(SingleAircraftEnv):
+    """gym_guidance_collision_avoidance_single/envs/SingleAircraft2Env.py (the packaged copy): action (a[0], a[1]) in
+    [-1, 1]^2 with heading += d_heading*a[0], speed += d_speed*a[1] (:281-285), its own reward literals and the
+    out-of-map termination 'w' (:155-176), info returned as a bare string (:134)."""
+    _variant = "continuous2"
+    _info_as_dict = False
+
+    def __init__(self, num_intruders=None, seed=None, device=None, rng="mt19937", precision="exact", config=PackagedConfig,
+                 **overrides):
+        super().__init__(num_intruders, seed, device, rng, precision, config, **overrides)
+
+    def _encode_action(self, action):
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        assert a.shape == (2,) and (a >= -1).all() and (a <= 1).all(), "given action is in incorrect shape"   # :127
+        return np.asarray([[a[0], a[1]]], dtype=np.float32)
 
 
 class SingleAircraftMCTSEnv(SingleAircraftEnv):

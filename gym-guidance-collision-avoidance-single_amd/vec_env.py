@@ -56,8 +56,8 @@ class UamVecEnv:
         self.num_envs, self.observation_space, self.action_space = v.num_envs, v.observation_space, v.action_space
         B, D = v.num_envs, v.obs_dim
         am = v.cfg.action_mode
-        act_shape = (B, 2) if am == capi.ACT_PAIR else (B,)
-        act_dt = torch.float32 if am == capi.ACT_CONTINUOUS1 else torch.int32
+        act_shape = (B, 2) if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else (B,)
+        act_dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
         pin = dict(pin_memory=True)
         self._h_act = torch.empty(act_shape, dtype=act_dt, **pin)
         self._d_act = torch.empty(act_shape, dtype=act_dt, device=v.device)

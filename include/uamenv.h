@@ -65,8 +65,11 @@ enum {
     UAM_ACT_DISCRETE9   = 0, /* int32[B]; a0 = a/3, a1 = a%3            SingleAircraftEnv.py:128-131 */
     UAM_ACT_PAIR        = 1, /* int32[B,2]; (a0, a1) used un-decoded     SingleAircraftMCTSEnv.py:126-134 */
     UAM_ACT_CONTINUOUS1 = 2, /* float32[B]; heading += d_heading*(a-1), no speed command  SingleAircraft2Env.py:294-298 */
-    UAM_ACT_DISCRETE3   = 3  /* int32[B] in {0,1,2}; heading += d_heading*(a-1), no speed command
+    UAM_ACT_DISCRETE3   = 3, /* int32[B] in {0,1,2}; heading += d_heading*(a-1), no speed command
                                 SingleAircraftDiscrete3HEREnv.py:43,406-414 */
+    UAM_ACT_CONTINUOUS2 = 4  /* float32[B,2]; heading += d_heading*a[0], speed += d_speed*a[1] (no offset, live speed
+                                command): the packaged copy gym_guidance_collision_avoidance_single/envs/
+                                SingleAircraft2Env.py:281-285 (action_space Box(-1, 1, (2,)), :35) */
 };
 
 /* ---- intruder dynamics ---- */

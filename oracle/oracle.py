@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
-ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3 = 0, 1, 2, 3
+ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3, ACT_CONTINUOUS2 = 0, 1, 2, 3, 4
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
 RNG_PHILOX, RNG_MT19937 = 0, 1
 POS_F32, POS_EXACT = 0, 1
@@ -222,6 +222,8 @@ class OracleBatch:
         am = self.cfg.action_mode
         if am == ACT_CONTINUOUS1:
             return np.ascontiguousarray(actions, dtype=np.float32).reshape(self.B)
+        if am == ACT_CONTINUOUS2:
+            return np.ascontiguousarray(actions, dtype=np.float32).reshape(self.B, 2)
         if am == ACT_PAIR:
             return np.ascontiguousarray(actions, dtype=np.int32).reshape(self.B, 2)
         return np.ascontiguousarray(actions, dtype=np.int32).reshape(self.B)

@@ -627,6 +627,11 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
     } else if (g->action_mode == UAM_ACT_DISCRETE3) {
         a0 = (double)((const int32_t*)actions)[eidx];        /* Discrete3HEREnv.py:408: heading += d_heading * (a - 1) */
         has_speed = 0;
+    } else if (g->action_mode == UAM_ACT_CONTINUOUS2) {
+        /* packaged copy, envs/SingleAircraft2Env.py:281-285: heading += d_heading * a[0]; speed += d_speed * a[1].
+         * own_step applies (a - 1): feed it a + 1, exact for the float32-valued actions the boundary carries */
+        a0 = (double)((const float*)actions)[2 * eidx] + 1.0;
+        a1 = (double)((const float*)actions)[2 * eidx + 1] + 1.0;
     } else {
         a0 = (double)((const float*)actions)[eidx];
         has_speed = 0;

@@ -33,7 +33,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-INFO = {"": 0, "c": 1, "g": 2, "n": 3}
+INFO = {"": 0, "c": 1, "g": 2, "n": 3, "w": 4}
 
 
 # ----------------------------------------------------------------------------- gym stub
@@ -211,7 +211,7 @@ def save(name, meta, data):
     payload.update(data)
     np.savez_compressed(path, **payload)
     codes = data.get("info")
-    summ = "" if codes is None else " codes=" + str(np.bincount(np.asarray(codes).ravel(), minlength=4).tolist())
+    summ = "" if codes is None else " codes=" + str(np.bincount(np.asarray(codes).ravel(), minlength=5).tolist())
     prom = data.get("promoted")
     if prom is not None:
         summ += " promoted_frac=%.4f" % float(np.mean(prom))
@@ -388,6 +388,57 @@ def g8_continuous(Config, m_env2):
                                         dynamics=0), data)
 
 
+def g8b_packaged_continuous2(ref):
+    """G8 'second mode': the PACKAGED copy gym_guidance_collision_avoidance_single/envs/SingleAircraft2Env.py — action
+    (a[0], a[1]) un-offset with a live speed command (:281-285), its own reward literals (NMAC -5, conflict -1,
+    goal +1) and the out-of-map termination 'w' (-100, :169-170), heading_sigma 2 degrees (envs/config.py).  The module
+    uses a relative import (`from .config import Config`): it is loaded under a throw-away package name."""
+    import importlib
+    import types
+    pkg_dir = os.path.join(ref, "gym_guidance_collision_avoidance_single", "envs")
+    pkg = types.ModuleType("_gcas_packaged_envs")
+    pkg.__path__ = [pkg_dir]
+    sys.modules["_gcas_packaged_envs"] = pkg
+    m = importlib.import_module("_gcas_packaged_envs.SingleAircraft2Env")
+    PConfig = importlib.import_module("_gcas_packaged_envs.config").Config
+    N = 8
+    PConfig.intruder_size = N
+    np.random.seed(17)
+    env = m.SingleAircraft2Env()
+    obs0 = env.reset()
+    st0 = snapshot(env)
+    arng = np.random.RandomState(98)   # private stream for the action noise
+    episodes = [0]
+    real_reset = env.reset
+
+    def counting_reset():
+        episodes[0] += 1
+        return real_reset()
+    env.reset = counting_reset
+
+    def act(t, e):
+        d = e.drone
+        x, y = float(d.position[0]), float(d.position[1])
+        if episodes[0] % 2 == 1:                      # every other episode heads for the nearest map edge: the 'w' rule
+            tx, ty = (x, -50.0) if y < x else (-50.0, y)
+        else:
+            tx, ty = e.goal.position[0], e.goal.position[1]
+        bearing = math.atan2(ty - y, tx - x)
+        diff = (bearing - float(d.heading) + math.pi) % (2 * math.pi) - math.pi
+        a0 = np.clip(diff / PConfig.d_heading + arng.normal(0, 0.3), -1, 1)
+        a1 = np.clip(arng.uniform(-1, 1), -1, 1)
+        return np.array([np.float32(a0), np.float32(a1)], dtype=np.float64)   # float32-valued, like the C-ABI carries
+
+    data = run_episode_stream(env, act, 900, 20)
+    data["obs0"] = np.asarray(obs0)
+    add_prefixed(data, "st0_", st0)
+    data["actions"] = np.asarray(data["actions"], dtype=np.float32)
+    save("g8b_packaged_continuous2_n8_seed17",
+         dict(seed=17, N=N, variant="packaged SingleAircraft2Env", obs_mode=0, action_mode=4, dynamics=0,
+              heading_sigma=PConfig.heading_sigma, speed_sigma=PConfig.speed_sigma, nmac_penalty=-5.0,
+              conflict_penalty=-1.0, wall_penalty=-100.0, goal_reward=1.0, wall_terminates=1), data)
+
+
 def g9_randintruder(Config, m_ri, N, seed, T):
     """G9: RandIntruder env: constant drift, Bernoulli heading changes (also on terminal steps), raw
     6-wide obs, pair actions."""
@@ -492,6 +543,7 @@ def main():
     hand_placed(Config, m_env, "g5_conflict_masks_goal", 8, 23, place_g5, 12,
                 "conflict masks goal until the intruder leaves")
     g8_continuous(Config, m_env2)
+    g8b_packaged_continuous2(args.ref)
     g9_randintruder(Config, m_ri, 8, 13, 1500)
     g9_randintruder(Config, m_ri, 64, 14, 500)
     g9b_mctsenv(Config, m_mcts)
@@ -500,4 +552,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8b":       # only the packaged-copy fixture
+        sys.dont_write_bytecode = True
+        install_gym_stub()
+        g8b_packaged_continuous2("/root/reference")
+    else:
+        main()

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAJECTORY_FIXTURES = [
     "g1_discrete9_n4_seed0", "g2_goalseek_n8_seed3", "g2_goalseek_n32_seed1", "g2_goalseek_n80_seed4",
     "g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal",
-    "g8_continuous_n8_seed7", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
+    "g8_continuous_n8_seed7", "g8b_packaged_continuous2_n8_seed17", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
     "g9b_mctsenv_n8_seed11", "g6b_randomenv_n8_seed31",
 ]
 
@@ -34,9 +34,11 @@ def config_overrides(fx, **extra):
     """uam_config field overrides encoded in a fixture's meta_* entries."""
     over = dict(obs_mode=int(fx["meta_obs_mode"]), action_mode=int(fx["meta_action_mode"]),
                 dynamics=int(fx["meta_dynamics"]), seed=int(fx["meta_seed"]))
-    for k in ("heading_sigma", "speed_sigma"):
+    for k in ("heading_sigma", "speed_sigma", "nmac_penalty", "conflict_penalty", "wall_penalty", "goal_reward"):
         if "meta_" + k in fx:
             over[k] = float(fx["meta_" + k])
+    if "meta_wall_terminates" in fx:          # the packaged 2Env ends the episode when the ownship leaves the map
+        over["wall_terminates"] = int(fx["meta_wall_terminates"])
     if "meta_random_own_start" in fx:
         over["random_own_start"] = int(fx["meta_random_own_start"])
     if int(fx["meta_obs_mode"]) == 3:   # HER family

@@ -26,6 +26,8 @@ def goal_seek_actions(st, d_heading, action_mode):
         return np.stack([a0, a1], axis=1).astype(np.int32)
     if action_mode == 3:
         return a0
+    if action_mode == 4:      # packaged 2Env: un-offset heading command, full throttle
+        return np.stack([np.clip(diff / d_heading, -1, 1), np.ones_like(diff)], axis=1).astype(np.float32)
     return np.clip(1.0 + diff / d_heading, -1, 1).astype(np.float32)
 
 
@@ -36,6 +38,8 @@ def random_actions(rs, B, action_mode):
         return rs.randint(0, 3, size=(B, 2)).astype(np.int32)
     if action_mode == 3:
         return rs.randint(0, 3, size=B).astype(np.int32)
+    if action_mode == 4:
+        return rs.uniform(-1, 1, size=(B, 2)).astype(np.float32)
     return rs.uniform(-1, 1, size=B).astype(np.float32)
 
 

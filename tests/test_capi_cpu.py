@@ -94,7 +94,7 @@ def test_variant_configs_follow_the_reference_classes(capi):
     """Host logic (no GPU): every variant name maps to the obs/action/dynamics combination of its reference class."""
     import uamenv
     want = {  # variant: (obs_mode, action_mode, dynamics, random_own_start, obs_dim at N=8)
-        "discrete9": (0, 0, 0, 0, 40), "continuous": (0, 2, 0, 0, 40), "mcts": (1, 1, 0, 0, 40),
+        "discrete9": (0, 0, 0, 0, 40), "continuous": (0, 2, 0, 0, 40), "continuous2": (0, 4, 0, 0, 40), "mcts": (1, 1, 0, 0, 40),
         "randintruder": (2, 1, 1, 0, 56), "random_start": (0, 0, 0, 1, 40), "her9": (3, 0, 0, 1, 28), "her3": (3, 3, 0, 1, 28),
     }
     for variant, (om, am, dyn, ros, D) in want.items():
@@ -109,6 +109,10 @@ def test_variant_configs_follow_the_reference_classes(capi):
         sparse_reward = True
     assert uamenv.make_config(4, 8, variant="her9", config=Sparse).wall_terminates == 1      # Discrete9HEREnv.py:217-221
     assert uamenv.make_config(4, 8, variant="discrete9", config=Sparse).wall_terminates == 0
+    # the packaged copy's constants (envs/config.py + the literals of its _terminal_reward)
+    pk = uamenv.make_config(4, 8, variant="continuous2", config=uamenv.PackagedConfig)
+    assert (pk.nmac_penalty, pk.conflict_penalty, pk.wall_penalty, pk.goal_reward, pk.wall_terminates) == (-5, -1, -100, 1, 1)
+    assert pk.heading_sigma == np.radians(2) and pk.action_mode == 4
     with pytest.raises(AttributeError):
         uamenv.make_config(4, 8, no_such_field=1)
 

@@ -52,7 +52,7 @@ def test_philox_exact_promotion_matches_oracle(uamenv, oracle, B, N, T):
     assert out["redraws"] > 0, "no promotion exercised"
 
 
-@pytest.mark.parametrize("variant,N", [("continuous", 8), ("mcts", 8), ("randintruder", 8), ("randintruder", 64),
+@pytest.mark.parametrize("variant,N", [("continuous", 8), ("continuous2", 32), ("mcts", 8), ("randintruder", 8), ("randintruder", 64),
                                        ("random_start", 8)])
 @pytest.mark.parametrize("precision", ["f32", "exact"])
 def test_variants_match_oracle(uamenv, oracle, variant, N, precision):
@@ -78,7 +78,8 @@ def test_mt19937_matches_oracle(uamenv, oracle, variant, N, T):
 
 
 # ---------------------------------------------------------------- against the reference's own trajectories
-VARIANT_OF = {(0, 0, 0): "discrete9", (0, 2, 0): "continuous", (1, 1, 0): "mcts", (2, 1, 1): "randintruder"}
+VARIANT_OF = {(0, 0, 0): "discrete9", (0, 2, 0): "continuous", (1, 1, 0): "mcts", (2, 1, 1): "randintruder",
+              (0, 4, 0): "continuous2"}
 
 
 @pytest.mark.parametrize("name", gu.TRAJECTORY_FIXTURES)
@@ -90,7 +91,10 @@ def test_gpu_replays_reference_fixture_from_seed(uamenv, name):
     variant = VARIANT_OF[(int(fx["meta_obs_mode"]), int(fx["meta_action_mode"]), int(fx["meta_dynamics"]))]
     if int(fx.get("meta_random_own_start", 0)):
         variant = "random_start"          # Simulators/SingleAircraftRandomEnv.py
-    over = {k: float(fx["meta_" + k]) for k in ("heading_sigma", "speed_sigma") if "meta_" + k in fx}
+    over = {k: float(fx["meta_" + k]) for k in ("heading_sigma", "speed_sigma", "nmac_penalty", "conflict_penalty",
+                                                "wall_penalty", "goal_reward") if "meta_" + k in fx}
+    if "meta_wall_terminates" in fx:
+        over["wall_terminates"] = int(fx["meta_wall_terminates"])
     env = uamenv.BatchedSingleAircraftEnv(1, N, variant=variant, rng="mt19937", precision="exact",
                                           seed=int(fx["meta_seed"]), auto_reset=False, **over)
     raw = int(fx["meta_obs_mode"]) != 0
@@ -239,6 +243,29 @@ def test_gym_style_env_is_a_drop_in(uamenv):
 
 
 # ---------------------------------------------------------------- API behaviour
+def test_packaged_2env_gym_class_is_a_drop_in(uamenv):
+    """gym_guidance_collision_avoidance_single/envs/SingleAircraft2Env.py through the gym-style class: (a0, a1) action,
+    bare-string info, its reward literals and the 'w' rule — the first episodes of the g8b fixture from seed(17)."""
+    fx = gu.load("g8b_packaged_continuous2_n8_seed17")
+    env = uamenv.PackagedSingleAircraft2Env(num_intruders=8)
+    assert env.action_space.shape == (2,) and env.observation_space.shape == (40,)
+    env.seed(17)
+    assert np.abs(env.reset() - fx["obs0"]).max() <= 1e-5
+    reset_steps = {int(t): i for i, t in enumerate(fx["reset_steps"])}
+    seen = set()
+    for t in range(400):
+        ob, r, d, info = env.step(fx["actions"][t])
+        assert isinstance(info, str) and info == ["", "c", "g", "n", "w"][int(fx["info"][t])], t
+        assert d == bool(fx["done"][t]) and abs(r - fx["reward"][t]) <= 1e-5 and np.abs(ob - fx["obs"][t]).max() <= 1e-5, t
+        seen.add(info)
+        if d:
+            assert np.abs(env.reset() - fx["reset_obs"][reset_steps[t]]).max() <= 1e-5
+    assert "w" in seen, "the out-of-map termination was not exercised"
+    with pytest.raises(AssertionError):
+        env.step([2.0, 0.0])
+    env.close()
+
+
 def test_reset_mask_state_roundtrip_and_step_many(uamenv, oracle):
     import torch
     B, N = 64, 8

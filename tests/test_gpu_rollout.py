@@ -110,6 +110,8 @@ def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
     ("randintruder", 2048, 64, 10, "goal"),
     ("discrete9", 1000, 32, 12, "random"),
     ("mcts", 3000, 20, 9, "random"),            # pair actions
+    ("continuous2", 2048, 16, 14, "goal"),      # float pair actions (the packaged 2Env's semantics)
+    ("continuous2", 777, 8, 10, "random"),
     ("discrete9", 32768, 32, 6, "goal"),        # the flavour without ownship wave
     ("discrete9", 65536, 32, 3, "goal"),        # not fused: a policy launch and a step launch per step
 ])
