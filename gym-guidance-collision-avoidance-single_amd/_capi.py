@@ -154,6 +154,13 @@ def lib():
             raise ImportError(
                 "%s not found: build it with `make -C %s` (or __graft_entry__.build()); "
                 "uamenv has no CPU fallback" % (LIB_PATH, CSRC))
+        # Load order matters in a process that also uses torch: torch ships its own HIP runtime, and whichever
+        # libamdhip64 is mapped first is the one both end up talking to.  Loading ours first left uam_create without
+        # a visible device once torch came in ("no ROCm-capable device"); torch first works in every order of use.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)   # AttributeError if the library does not export the declared symbol
