@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("UAMENV_LIB") or os.path.join(CSRC, "libuamenv_hip.so"
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
 ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3, ACT_CONTINUOUS2 = 0, 1, 2, 3, 4
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
-RNG_PHILOX, RNG_MT19937 = 0, 1
+RNG_PHILOX, RNG_MT19937, RNG_MT19937_SHARED = 0, 1, 2
 POS_F32, POS_EXACT = 0, 1
 INFO_CODES = ("", "c", "g", "n", "w")   # SingleAircraftEnv.py:168,172,180,183
 

@@ -44,6 +44,7 @@ struct uam_env {
     int num_cus;                /* compute units of the device (hipDeviceProp_t::multiProcessorCount) */
     int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
+    bool shared_stream;         /* UAM_RNG_MT19937_SHARED: cfg.rng_mode is normalised to UAM_RNG_MT19937, every env uses stream 0 */
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
     int Tm, Em;                 /* looped kernel: sweeping threads per block (+ 64 for its ownship wave), envs per block <= 64 */
@@ -138,7 +139,9 @@ static int validate(const uam_config* c)
     if (c->shaped_reward && c->dynamics == UAM_DYN_RANDINTRUDER)
         return fail(UAM_EINVAL, "shaped_reward is not defined for the RandIntruder dynamics");
     if (c->dynamics < 0 || c->dynamics > UAM_DYN_RANDINTRUDER) return fail(UAM_EINVAL, "bad dynamics %d", c->dynamics);
-    if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
+    if (c->rng_mode < 0 || c->rng_mode > UAM_RNG_MT19937_SHARED) return fail(UAM_EINVAL, "bad rng_mode %d", c->rng_mode);
+    if (c->rng_mode == UAM_RNG_MT19937_SHARED && c->num_envs > 1024)
+        return fail(UAM_EINVAL, "the shared stream is serial across envs (one launch per env and call): num_envs <= 1024, got %d", c->num_envs);
     if (c->precision < 0 || c->precision > UAM_POS_EXACT) return fail(UAM_EINVAL, "bad precision %d", c->precision);
     if (c->fuse_rollout < 0 || c->fuse_rollout > UAM_FUSE_NEVER) return fail(UAM_EINVAL, "bad fuse_rollout %d", c->fuse_rollout);
     if (c->graph_safe && c->rng_mode != UAM_RNG_PHILOX) return fail(UAM_EINVAL, "graph_safe needs the Philox RNG");
@@ -260,6 +263,35 @@ static void fill_params(const uam_env* e, UamParams* p)
     p->many_policy = -1;
 }
 
+/* Parameters of a launch that covers the single env e0 of the batch (UAM_RNG_MT19937_SHARED: the envs take their
+ * turns on the one stream): every per-env / per-intruder pointer advanced to that env, B = 1 — and the MT19937 arrays
+ * left where they are, so that "env 0" of the view is always stream 0. */
+static void one_env_view(const uam_env* e, UamParams* p, int e0)
+{
+    const size_t io = (size_t)e0 * e->Np;
+    const bool x = e->cfg.precision == UAM_POS_EXACT;
+    p->s.px = x ? (void*)((double*)p->s.px + io) : (void*)((float*)p->s.px + io);
+    p->s.py = x ? (void*)((double*)p->s.py + io) : (void*)((float*)p->s.py + io);
+    p->s.vx += io; p->s.vy += io;
+    if (p->s.isp) { p->s.isp += io; p->s.ihd += io; }
+    p->s.qf += io / 4;
+    p->s.own_x += e0; p->s.own_y += e0; p->s.own_h += e0; p->s.own_s += e0; p->s.own_vx += e0; p->s.own_vy += e0;
+    p->s.goal_x += e0; p->s.goal_y += e0; p->s.no_conflict += e0; p->s.reset_count += e0;
+    if (p->s.nearest) p->s.nearest += e0;
+    if (p->s.ep_ret) { p->s.ep_ret += e0; p->s.ep_len += e0; p->s.ep_last_ret += e0; p->s.ep_last_len += e0; }
+    p->B = 1;
+    p->gid0 += (uint32_t)e0;
+    const size_t abytes = (e->cfg.action_mode == UAM_ACT_PAIR || e->cfg.action_mode == UAM_ACT_CONTINUOUS2) ? 8 : 4;
+    if (p->actions) p->actions = (const char*)p->actions + (size_t)e0 * abytes;
+    if (p->obs) p->obs += (size_t)e0 * e->D;
+    if (p->reward) p->reward += e0;
+    if (p->done) p->done += e0;
+    if (p->info) p->info += e0;
+    if (p->mask) p->mask += e0;
+    /* a single row keeps the wide-store path only if it stays 16-byte aligned */
+    if (p->obs && (((uintptr_t)p->obs & 15u) != 0)) p->obs_vec = 0;
+}
+
 static inline int grid_of(const uam_env* e) { return (e->cfg.num_envs + e->E - 1) / e->E; }
 static inline size_t lds_stage(const uam_env* e, const UamParams& p) { return p.obs_vec ? (size_t)e->E * e->D * 4 : 0; }
 
@@ -283,6 +315,9 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     uam_env* e = new uam_env();
     e->cfg = *cfg;
+    e->shared_stream = cfg->rng_mode == UAM_RNG_MT19937_SHARED;
+    if (e->shared_stream) e->cfg.rng_mode = UAM_RNG_MT19937;     /* same kernels; the host walks the envs in order */
+    cfg = &e->cfg;
     e->device = device_id;
     e->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->timing = false;
@@ -658,21 +693,21 @@ static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
 }
 
 template <bool POS64, int RNG, bool SH>
-static void launch_reset_ros(const uam_env* e, const UamParams& p, hipStream_t st)
+static void launch_reset_ros(const uam_env* e, const UamParams& p, hipStream_t st, int blocks)
 {
-    dim3 grid(grid_of(e)), block(e->T);
+    dim3 grid(blocks > 0 ? blocks : grid_of(e)), block(e->T);
     const size_t lds = lds_stage(e, p);
     if (e->cfg.random_own_start) hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, SH, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((uam_reset_kernel<POS64, RNG, SH, false>), grid, block, lds, st, p);
 }
 
-static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st)
+static void launch_reset(const uam_env* e, const UamParams& p, hipStream_t st, int blocks = 0)
 {
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937, sh = e->hold_sh != 0;
-    if (x && mt) { if (sh) launch_reset_ros<true, UAM_RNG_MT19937, true>(e, p, st); else launch_reset_ros<true, UAM_RNG_MT19937, false>(e, p, st); }
-    else if (x) { if (sh) launch_reset_ros<true, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<true, UAM_RNG_PHILOX, false>(e, p, st); }
-    else if (mt) { if (sh) launch_reset_ros<false, UAM_RNG_MT19937, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_MT19937, false>(e, p, st); }
-    else { if (sh) launch_reset_ros<false, UAM_RNG_PHILOX, true>(e, p, st); else launch_reset_ros<false, UAM_RNG_PHILOX, false>(e, p, st); }
+    if (x && mt) { if (sh) launch_reset_ros<true, UAM_RNG_MT19937, true>(e, p, st, blocks); else launch_reset_ros<true, UAM_RNG_MT19937, false>(e, p, st, blocks); }
+    else if (x) { if (sh) launch_reset_ros<true, UAM_RNG_PHILOX, true>(e, p, st, blocks); else launch_reset_ros<true, UAM_RNG_PHILOX, false>(e, p, st, blocks); }
+    else if (mt) { if (sh) launch_reset_ros<false, UAM_RNG_MT19937, true>(e, p, st, blocks); else launch_reset_ros<false, UAM_RNG_MT19937, false>(e, p, st, blocks); }
+    else { if (sh) launch_reset_ros<false, UAM_RNG_PHILOX, true>(e, p, st, blocks); else launch_reset_ros<false, UAM_RNG_PHILOX, false>(e, p, st, blocks); }
 }
 
 static int check_obs_ptr(const uam_env* e, const float* obs, UamParams* p)
@@ -692,6 +727,15 @@ extern "C" int uam_reset(uam_env* e, const uint8_t* mask_dev, float* obs_out, vo
     if (rc) return rc;
     p.mask = mask_dev;
     p.obs = obs_out;
+    if (e->shared_stream) {
+        for (int e0 = 0; e0 < e->cfg.num_envs; e0++) {      /* env after env on the one stream */
+            UamParams q = p;
+            one_env_view(e, &q, e0);
+            launch_reset(e, q, (hipStream_t)stream, 1);
+        }
+        HIP_TRY(hipGetLastError());
+        return UAM_OK;
+    }
     launch_reset(e, p, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return UAM_OK;
@@ -725,7 +769,15 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
         }
         p.noise = e->noise + (size_t)(e->step_index - e->noise_base) * e->cfg.num_envs;
     }
-    launch_step(e, p, st);
+    if (e->shared_stream) {
+        for (int e0 = 0; e0 < e->cfg.num_envs; e0++) {      /* DummyVecEnv order: env e0 steps (and resets) before e0+1 draws */
+            UamParams q = p;
+            one_env_view(e, &q, e0);
+            hipLaunchKernelGGL(e->step_kernel, dim3(1), dim3(e->T), lds_step(e, q.obs_vec != 0), st, q);
+        }
+    } else {
+        launch_step(e, p, st);
+    }
     HIP_TRY(hipGetLastError());
     e->step_index++;
     if (e->timing) e->timed_launches++;

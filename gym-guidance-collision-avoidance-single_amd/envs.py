@@ -83,7 +83,7 @@ _VARIANTS = {
     "her9": (capi.OBS_KNN5, capi.ACT_DISCRETE9, capi.DYN_STRAIGHT, 1),           # ...Discrete9HEREnv.py (k-nearest obs)
     "her3": (capi.OBS_KNN5, capi.ACT_DISCRETE3, capi.DYN_STRAIGHT, 1),           # ...Discrete3HEREnv.py (+ shaped reward)
 }
-_RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
+_RNG = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937, "mt19937_shared": capi.RNG_MT19937_SHARED}
 _PREC = {"f32": capi.POS_F32, "exact": capi.POS_EXACT}
 
 
@@ -271,7 +271,7 @@ class BatchedSingleAircraftEnv:
         raw = np.asarray(seeds)
         if raw.size == 0 or (raw.dtype.kind not in "ui") or (raw.dtype.kind == "i" and (raw < 0).any()):
             raise ValueError("seeds must be non-negative integers")
-        if self.cfg.rng_mode == capi.RNG_MT19937:
+        if self.cfg.rng_mode in (capi.RNG_MT19937, capi.RNG_MT19937_SHARED):
             if (raw.astype(np.uint64) >= np.uint64(1) << np.uint64(32)).any():
                 raise ValueError("Seed must be between 0 and 2**32 - 1")        # np.random.seed's own message
         elif raw.size > 1 and len(np.unique(raw)) > 1:
@@ -466,7 +466,7 @@ class BatchedSingleAircraftEnv:
     def get_state(self, fields=None):
         B, N = self.num_envs, self.intruder_size
         names = list(capi.STATE_FIELDS) if fields is None else list(fields)
-        if self.cfg.rng_mode != capi.RNG_MT19937:
+        if self.cfg.rng_mode not in (capi.RNG_MT19937, capi.RNG_MT19937_SHARED):
             names = [n for n in names if not n.startswith("mt_")]
         hold_sh = self.cfg.dynamics == capi.DYN_RANDINTRUDER or self.cfg.obs_mode == capi.OBS_RAW6
         if not hold_sh:

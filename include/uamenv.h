@@ -84,9 +84,14 @@ enum {
     UAM_RNG_PHILOX  = 0, /* counter-based Philox4x32-10 keyed by (seed; global env id, step index | episode
                             counter, purpose/intruder, attempt): order-free, sharding-invariant; the
                             throughput mode (scheme in DESIGN.md) */
-    UAM_RNG_MT19937 = 1  /* one NumPy-legacy MT19937 stream per env, consumed in the reference's draw order
+    UAM_RNG_MT19937 = 1, /* one NumPy-legacy MT19937 stream per env, consumed in the reference's draw order
                             (rk_double / polar rk_gauss with cache).  Env e seeded with s reproduces the
                             reference run in a process that called np.random.seed(s). */
+    UAM_RNG_MT19937_SHARED = 2 /* ONE such stream for the whole batch, consumed env after env in DummyVecEnv order
+                            (dummy_vec_env.py:47-55: env e steps — and resets, if done — before env e+1 draws): what B env
+                            objects in one reference process do to the global np.random after np.random.seed(s).
+                            Inherently serial across envs (B launches per call): for plumbing / parity runs of a few
+                            envs, num_envs <= 1024.  Stream 0 of the state view is the shared one. */
 };
 
 /* ---- position precision ---- */

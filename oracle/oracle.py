@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 OBS_NORM4, OBS_RAW4, OBS_RAW6, OBS_KNN5 = 0, 1, 2, 3
 ACT_DISCRETE9, ACT_PAIR, ACT_CONTINUOUS1, ACT_DISCRETE3, ACT_CONTINUOUS2 = 0, 1, 2, 3, 4
 DYN_STRAIGHT, DYN_RANDINTRUDER = 0, 1
-RNG_PHILOX, RNG_MT19937 = 0, 1
+RNG_PHILOX, RNG_MT19937, RNG_MT19937_SHARED = 0, 1, 2
 POS_F32, POS_EXACT = 0, 1
 MATH_LIBM, MATH_PORTABLE = 0, 1
 INFO_CODES = ["", "c", "g", "n", "w"]

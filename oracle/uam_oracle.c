@@ -697,6 +697,8 @@ orc_batch* orc_create(const uam_config* cfg, int math_impl, int shared_stream)
     if (!cfg || cfg->struct_size != sizeof(uam_config) || cfg->num_envs < 1 || cfg->num_intruders < 1) return NULL;
     orc_batch* b = (orc_batch*)calloc(1, sizeof(*b));
     b->cfg = *cfg;
+    if (b->cfg.rng_mode == UAM_RNG_MT19937_SHARED) { b->cfg.rng_mode = UAM_RNG_MT19937; shared_stream = 1; }   /* the product's spelling */
+    cfg = &b->cfg;
     b->math_impl = math_impl;
     b->shared = shared_stream && cfg->rng_mode == UAM_RNG_MT19937;
     b->B = cfg->num_envs;

@@ -807,3 +807,32 @@ def test_config5_randintruder_8192x64_steps_and_one_mcts_plan_match_oracle(uamen
         a = pu.random_actions(rs, B, 1)
     pu.compare_states(env.get_state(), orc.get_state(), "config 5 after 5 steps", hold_sh=True)
     env.close(); orc.close()
+
+
+# ---------------------------------------------------------------- G10: B envs on ONE NumPy stream, DummyVecEnv order
+def test_shared_stream_batch_replays_the_reference_process(uamenv, oracle):
+    """`rng="mt19937_shared"`: what four env objects in ONE reference process do to the global np.random after
+    np.random.seed(5), stepped round-robin with reset-on-done inside each env's turn (dummy_vec_env.py:47-55) —
+    "identical RNG seed" for a batch.  The fixture g10 was recorded that way from the reference."""
+    fx = gu.load("g10_shared_stream_b4_n8_seed5")
+    B, N = int(fx["meta_B"]), int(fx["meta_N"])
+    env = uamenv.BatchedSingleAircraftEnv(B, N, rng="mt19937_shared", precision="exact", seed=int(fx["meta_seed"]), auto_reset=True)
+    obs0 = env.reset().cpu().numpy()
+    assert np.abs(obs0 - fx["obs0"]).max() <= 1e-5
+    for t in range(fx["actions"].shape[0]):
+        obs, rew, done, infos = env.step(fx["actions"][t])
+        where = "g10 step %d" % t
+        assert np.array_equal(done.cpu().numpy().astype(np.uint8), fx["done"][t]), where
+        assert np.array_equal(infos.codes.cpu().numpy(), fx["info"][t]), where
+        assert np.abs(rew.cpu().numpy() - fx["reward"][t]).max() <= 1e-5, where
+        assert np.abs(obs.cpu().numpy() - fx["obs_after"][t]).max() <= 1e-5, where
+        nc = env.no_conflict.cpu().numpy()
+        assert np.array_equal(np.where(fx["done"][t] != 0, 0, nc), np.where(fx["done"][t] != 0, 0, fx["no_conflict"][t])), where
+    assert fx["done"].sum() > 0
+    env.close()
+    # and against the oracle in the same mode, bit for bit, at a larger batch and through the RandIntruder draws
+    pu.run_lockstep(uamenv, oracle, 24, 8, 120, policy="goal", rng="mt19937_shared", precision="exact", check_state_every=10)
+    pu.run_lockstep(uamenv, oracle, 6, 20, 60, policy="goal", rng="mt19937_shared", precision="exact", variant="randintruder",
+                    check_state_every=10)
+    with pytest.raises(uamenv.UamError):
+        uamenv.BatchedSingleAircraftEnv(2048, 8, rng="mt19937_shared", precision="exact")
