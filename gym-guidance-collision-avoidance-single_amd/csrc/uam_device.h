@@ -126,9 +126,16 @@ struct UamCold {
     double near_thr, near_coeff;  /* 3 * minimum_separation, Config.conflict_coeff (Discrete3HEREnv.py:225-226) */
 };
 
+/* The cold configuration is written once (uam_create) and only ever read by kernels: the CONSTANT address space tells the
+ * compiler so, and uniform reads of it become scalar loads (s_load) instead of vector-memory loads even inside divergent
+ * rare paths — which matters twice: no VGPRs for them, and no pending vector loads for the looped kernel's hot path to
+ * wait on (see UAM_DRAIN_RARE_LOADS). */
+typedef const __attribute__((address_space(4))) UamCold* UamColdPtr;
+typedef const __attribute__((address_space(4))) UamCold& UamColdRef;
+
 struct UamParams {
     UamDev s;
-    const UamCold* c;
+    UamColdPtr c;
     int B, N, Np, Q, L, lshift, E, D;
     int obs_mode, action_mode, auto_reset, sparse_reward, obs_w, obs_vec, track_ep, wall_term, knn, shaped;
     uint32_t seed_lo, seed_hi, gid0;
@@ -548,6 +555,13 @@ __device__ __forceinline__ void uam_philox_normals(uint32_t gid, uint32_t c_step
     zh = r * cs;
     zs = r * sn;
 }
+
+/* Looped kernel only: a rare path that issued vector-memory LOADS (cold configuration, counters) drains them before it
+ * rejoins the hot path.  Otherwise the registers those loads wrote stay "possibly pending" in the compiler's model at
+ * the loop's back edge, and it guards the hot path's first write to any of them with s_waitcnt vmcnt(0) — which, vmcnt
+ * being one in-order counter for loads and stores, makes EVERY step wait for the previous step's observation stores
+ * to be acknowledged (found in the ISA; 0.4 of 2.6 us per step at 8192 x 32). */
+#define UAM_DRAIN_RARE_LOADS() do { if constexpr (PERSIST) __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
 
 /* Philox step counter of env `env` for step k of this launch: the kernel argument, or (graph-safe handles) the env's
  * own counter in device memory — the same number, since every env takes every step */
@@ -1289,7 +1303,7 @@ __device__ __forceinline__ void own_inputs(const UamParams& p, const int e, cons
 
 /* the update itself: registers in, registers + the env's 48-byte LDS record out */
 template <bool KC>
-__device__ __forceinline__ void own_update(const UamParams& p, const UamCold& c, OwnRegs& r, const OwnIn& in, float4* sh)
+__device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, OwnRegs& r, const OwnIn& in, float4* sh)
 {
     const int ai0 = (int)in.w0, ai1 = (int)in.w1;
     const float af = __uint_as_float(in.w0);
@@ -1348,7 +1362,7 @@ __device__ __forceinline__ void own_update(const UamParams& p, const UamCold& c,
  * written out so that this kernel's register allocation (63 VGPRs, 8 waves/SIMD) does not depend on the looped
  * kernel's needs; tests/test_gpu_rollout.py and the step_many tests hold the two forms bit-identical. */
 template <int RNG, bool KC = false>
-__device__ __forceinline__ void own_compute(const UamParams& p, const UamCold& c, const int e, float4* sh, const int k = 0,
+__device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, const int e, float4* sh, const int k = 0,
                                             MtHdr* mt_hdr = nullptr, const uint32_t* mt_win = nullptr)
 {
     /* the cold configuration arrives BY VALUE (kernarg, scalar loads, no aliasing with the stores
@@ -1617,7 +1631,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
 
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
-        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = uam_step_of(pk, env, k); rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
+        if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = PERSIST ? pk.step_index + (uint32_t)k : uam_step_of(pk, env, k);   /* (no graph-safe counter load in the looped kernel) */ rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
@@ -1627,7 +1641,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             vel_dirty = true; sp_dirty = true;
         }
     } else if (env_ok) {
-        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = PERSIST ? p.step_index + (uint32_t)k : uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         uint32_t pend = 0;                  /* my slots whose velocity is still to be computed */
@@ -1693,7 +1707,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     /* ---- RandIntruder: _update_headings after the reward, also on terminal steps (:162,166-174,332-336) */
     if (RI && env_ok) {
         if constexpr (RNG == UAM_RNG_PHILOX) {
-            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+            rng.gid = p.gid0 + (uint32_t)env; rng.c_step = PERSIST ? p.step_index + (uint32_t)k : uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
             /* one Philox block per quad: word j is intruder j's Bernoulli uniform u; a change takes its second
              * uniform as u / hc_prob (uniform on [0,1) given u < hc_prob) */
             if (quad_ok) {
@@ -1764,6 +1778,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             if (done) { p.s.ep_last_ret[env] = r; p.s.ep_last_len[env] = l; }
             p.s.ep_ret[env] = done ? 0.0 : r;
             p.s.ep_len[env] = done ? 0 : l;
+            UAM_DRAIN_RARE_LOADS();
         }
     }
 
@@ -1782,7 +1797,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = uam_step_of(pk, env, k); rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
+        rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = PERSIST ? pk.step_index + (uint32_t)k : uam_step_of(pk, env, k);   /* (no graph-safe counter load in the looped kernel) */ rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
         reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true; sp_dirty = true;
         if constexpr (PERSIST) {
@@ -1791,6 +1806,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
              * must have reached L2 before the mark is seen */
             if (gl == 0) { __threadfence(); ((uint32_t*)(lds_share + 3 * g))[3] = 0xFFFFFFFFu; }
         }
+        UAM_DRAIN_RARE_LOADS();
     }
     if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
 

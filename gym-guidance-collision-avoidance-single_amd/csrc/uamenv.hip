@@ -229,7 +229,7 @@ static void fill_params(const uam_env* e, UamParams* p)
     const uam_config& c = e->cfg;
     memset(p, 0, sizeof(*p));
     p->s = e->s;
-    p->c = e->cold;
+    p->c = (UamColdPtr)e->cold;
     p->B = c.num_envs; p->N = c.num_intruders; p->Np = e->Np; p->Q = e->Q; p->L = e->L; p->lshift = e->lshift;
     p->E = e->E; p->D = e->D;
     p->obs_mode = c.obs_mode; p->action_mode = c.action_mode; p->auto_reset = c.auto_reset;
