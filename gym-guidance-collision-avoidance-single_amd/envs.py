@@ -399,6 +399,37 @@ class BatchedSingleAircraftEnv:
         """K if a chunk of K steps runs as one launch of the looped kernel on this handle, else 1."""
         return int(self._lib.uam_steps_per_launch(self._h, int(K)))
 
+    def bind_rollout(self, action_tape, rew_out, done_out, info_out=None, obs_out=None):
+        """`rollout_into` with the argument checks and pointer extraction done ONCE: returns a zero-argument callable
+        that only makes the C call on the stream that is current now.  For hot loops that replay the same buffers
+        (a rollout slab ring): the checks cost ~25 us of Python per call, a tenth of a 20-step chunk at 65536 envs."""
+        torch = self._torch
+        if obs_out is None:
+            obs_out = self._obs.view(1, self.num_envs, self.obs_dim)
+        K = int(action_tape.shape[0])
+        am = self.cfg.action_mode
+        dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
+        if action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous() \
+                or action_tape.numel() != K * self._act_numel:
+            raise ValueError("action tape must be a contiguous device tensor [K, B(,2)] of %s" % dt)
+        for t, tdt in ((rew_out, torch.float32), (done_out, torch.uint8), (info_out, torch.uint8)):
+            if t is not None and (t.dtype != tdt or t.numel() != K * self.num_envs or not t.is_contiguous() or t.device != self.device):
+                raise ValueError("rollout slabs must be contiguous device tensors [K, B]")
+        if obs_out.dtype != torch.float32 or obs_out.dim() != 3 or tuple(obs_out.shape[1:]) != (self.num_envs, self.obs_dim) \
+                or not obs_out.is_contiguous() or obs_out.device != self.device:
+            raise ValueError("obs_out must be a contiguous device tensor float32[R, B, D]")
+        fn, h = self._lib.uam_rollout, self._h
+        args = (h, K, C.c_void_p(action_tape.data_ptr()), C.c_void_p(obs_out.data_ptr()), int(obs_out.shape[0]),
+                C.c_void_p(rew_out.data_ptr()), C.c_void_p(done_out.data_ptr()),
+                C.c_void_p(info_out.data_ptr()) if info_out is not None else None, self._stream())
+        keep = (action_tape, rew_out, done_out, info_out, obs_out)
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc:
+                capi.check(rc)
+        return call
+
     def observe(self):
         capi.check(self._lib.uam_observe(self._h, self._obs.data_ptr(), self._stream()))
         return self._obs
