@@ -156,6 +156,10 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
                                           auto_reset=True, device=ctx.local_rank, env_id_offset=first, fuse_rollout=fuse)
     dev = env.device
     env.reset()
+    if args.chunk <= 0 and int(env.steps_per_launch(K)) == 1 and ctx.world > 1 and steps < 4 * K:
+        # a short region of single-step launches: four chunks (and four small slabs) instead of one, so that only the last
+        # quarter's exchange is exposed at the closing barrier; chunking costs nothing here, the launches are the same
+        K = max(4, -(-steps // 4))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + ctx.rank)
     am = env.cfg.action_mode
