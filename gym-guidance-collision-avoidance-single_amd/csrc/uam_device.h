@@ -280,6 +280,7 @@ __device__ __forceinline__ void mt_load_lds(const UamDev& s, int e, const MtHdr*
 __device__ __forceinline__ void mt_store_lds(MtHdr* h, const MtCtx& m)
 {
     h->pos = m.pos; h->gen = m.gen; h->has_gauss = m.has_gauss; h->gauss = m.gauss;
+    h->win_base = m.win_base;
     h->win_len = m.win_len;      /* 0 once the cursor has left the window's round */
 }
 __device__ __forceinline__ uint32_t mt_temper(uint32_t v)
@@ -406,18 +407,18 @@ __device__ __forceinline__ uint32_t mt_u32(MtCtx& m)
  * cursor: the ownship thread (another wave) draws its two normals from it, then the group carries on.  A draw costs an
  * LDS read instead of three dependent, uncoalesced global loads and a store per word.  The window stops at the end of
  * the round. */
+template <int U = 4>
 __device__ __forceinline__ void mt_window_fill(const UamDev& s, const int e, const int gl, const int L, const int W,
-                                               uint32_t* win, MtHdr* hdr)
+                                               uint32_t* win, MtCtx& m)
 {
     uint32_t* key = s.mt_key + (size_t)e * UAM_MT_N;
     int pos = s.mt_pos[e], gen = s.mt_gen[e];
+    m.has_gauss = s.mt_has_gauss[e]; m.gauss = s.mt_gauss[e];      /* (same address across the group: one broadcast load each) */
     if (pos >= UAM_MT_N) { pos = 0; gen = 0; }
     const int len = min(W, UAM_MT_N - pos);
-    mt_twist_span(key, pos, gen, len, gl, L, (UAM_LDS_U32W)win);
-    if (gl == 0) {
-        hdr->pos = pos; hdr->gen = max(gen, pos + len); hdr->has_gauss = s.mt_has_gauss[e]; hdr->gauss = s.mt_gauss[e];
-        hdr->win_base = pos; hdr->win_len = len;
-    }
+    mt_twist_span<U>(key, pos, gen, len, gl, L, (UAM_LDS_U32W)win);
+    m.key = key; m.pos = pos; m.gen = max(gen, pos + len);
+    m.win = (UAM_LDS_U32)win; m.win_base = pos; m.win_len = len; m.cap = 0; m.gl = gl; m.L = L;
 }
 
 __device__ inline double mt_double(MtCtx& m)
@@ -1303,7 +1304,8 @@ __device__ __forceinline__ void own_inputs(const UamParams& p, const int e, cons
 
 /* the update itself: registers in, registers + the env's 48-byte LDS record out */
 template <bool KC>
-__device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, OwnRegs& r, const OwnIn& in, float4* sh)
+__device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, OwnRegs& r, const OwnIn& in, float4* sh,
+                                           const bool writes = true)
 {
     const int ai0 = (int)in.w0, ai1 = (int)in.w1;
     const float af = __uint_as_float(in.w0);
@@ -1353,9 +1355,11 @@ __device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, Own
         t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
     }
     r.ox = ox; r.oy = oy; r.hd = hd; r.sp = sp; r.vx = vx; r.vy = vy;
-    sh[0] = make_float4(ox, oy, rew, __uint_as_float(wall ? 2u : (hit ? 1u : 0u)));   /* tail code: 0 none, 1 goal, 2 wall */
-    sh[1] = make_float4(t[0], t[1], t[2], t[3]);
-    sh[2] = make_float4(t[4], t[5], t[6], t[7]);
+    if (writes) {
+        sh[0] = make_float4(ox, oy, rew, __uint_as_float(wall ? 2u : (hit ? 1u : 0u)));   /* tail code: 0 none, 1 goal, 2 wall */
+        sh[1] = make_float4(t[0], t[1], t[2], t[3]);
+        sh[2] = make_float4(t[4], t[5], t[6], t[7]);
+    }
 }
 
 /* single-step form (uam_sweep_kernel): load, update, store in one function — the same arithmetic as own_update,
@@ -1495,27 +1499,47 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     uint32_t* const mt_win_base = (uint32_t*)(mt_hdr_base + p.E);
     if constexpr (PERSIST) {
         if (env_first >= p.B) return;
+    } else if constexpr (RNG == UAM_RNG_MT19937) {
+        /* The MT19937 instances are latency-bound at 3 waves/SIMD (the stream bookkeeping costs the registers), and
+         * what sets a launch's time is its slowest wave.  So the head of the step is WAVE-LOCAL and issues every
+         * independent load before the first dependent one: the quad, the env's ownship state and action, the stream
+         * cursor; then the key words the cursor points at (the env's lane group twists its next window into LDS).
+         * Every lane of the group then runs the ownship phase of ITS env redundantly (same instructions, same values:
+         * for the wave it costs what one lane costs) — the two normals come from the window with the group's
+         * cooperative refill behind them (a single ownship thread past its window drew one word per three dependent
+         * memory round trips: ~1e-4 of env-steps, i.e. a few 25 us stragglers in every launch at 65536 envs), and no
+         * wave waits at a block barrier for another wave's envs. */
+        const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        OwnRegs orr; OwnIn oin;
+        if (env_ok) { own_load(pko, env, orr); own_fetch_inputs<RNG>(pko, env, k, oin); }
+        quad_load<POS64, SH>(p, base, quad_ok, q);
+        if (env_ok) {
+            MtCtx hm;
+            mt_window_fill<8>(p.s, env, gl, L, p.mt_first, mt_win_base + (size_t)g * p.mt_win, hm);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            hm.cap = min(p.mt_win, max(4 * L, 16));
+            oin.zh = mt_gauss(hm);   /* nothing else draws between the two normals */
+            oin.zs = mt_gauss(hm);
+            own_update<KC>(pko, *pko.c, orr, oin, lds_share + 3 * g, gl == 0);
+            if (gl == 0) { own_store(pko, env, orr); mt_store_lds(mt_hdr_base + g, hm); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (env_first >= p.B) return;                /* whole wave past the batch end */
     } else {
         /* threads that run the ownship phase fetch their quad AFTER it, so the fp64 phase and the
          * quad never share the register file (keeps the kernel at 64 VGPRs = 8 waves/SIMD); every
          * other thread has its loads in flight while it waits at the barrier */
         const bool does_own = tid < p.E;
-        if constexpr (RNG == UAM_RNG_MT19937) {
-            /* every lane group twists its env's next window of the NumPy stream ahead, into LDS; one barrier later
-             * the ownship threads draw their normals from it */
-            if (env_ok) mt_window_fill(p.s, env, gl, L, p.mt_first, mt_win_base + (size_t)g * p.mt_win, mt_hdr_base + g);
-            __syncthreads();
-        }
         if (!does_own) quad_load<POS64, SH>(p, base, quad_ok, q);
         if (does_own) {
             const int e = blockIdx.x * p.E + tid;
             /* cold configuration through the pointer: its scalar loads (and SGPRs) stay inside this branch */
             const UamParams& pko = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();   /* see `pk` below */
-            if constexpr (RNG == UAM_RNG_MT19937) {
-                if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k, mt_hdr_base + tid, mt_win_base + (size_t)tid * p.mt_win);
-            } else {
-                if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k);
-            }
+            if (e < p.B) own_compute<RNG, KC>(pko, *pko.c, e, lds_share + 3 * tid, k);
             quad_load<POS64, SH>(p, base, quad_ok, q);
         }
         __syncthreads();
@@ -1624,7 +1648,9 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         /* the cursor as the ownship thread left it; every lane of the group draws the same words from here on */
         if (env_ok) {
             rng.load_lds(p.s, env, mt_hdr_base + g, mt_win_base + (size_t)g * p.mt_win);
-            rng.m.cap = p.mt_win; rng.m.gl = gl; rng.m.L = L;     /* the group refills its window together */
+            /* the group refills its window together; respawns take one chunk (one memory round trip) at a time,
+             * the reset raises this to the window's capacity */
+            rng.m.cap = min(p.mt_win, max(4 * L, 16)); rng.m.gl = gl; rng.m.L = L;
             mt_used = true;
         }
     }
@@ -1797,6 +1823,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
     if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
         if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
+        if constexpr (RNG == UAM_RNG_MT19937) rng.m.cap = rng.m.cap ? p.mt_win : 0;      /* 8 N words: full refills */
         rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = PERSIST ? pk.step_index + (uint32_t)k : uam_step_of(pk, env, k);   /* (no graph-safe counter load in the looped kernel) */ rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
         reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true; sp_dirty = true;
