@@ -48,12 +48,20 @@
 #define UAM_STAMP 0
 #endif
 #if UAM_STAMP
-#define UAM_NSTAMP 10
+#define UAM_NSTAMP 16
 #define UAM_STAMP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     stamp_acc[i] += t_ - stamp_last; stamp_last = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define UAM_STAMP_AT(i) do { } while (0)
 #endif
+/* LDS written by some lanes of a wave, read by others of the SAME wave: the LDS unit serves a wave's operations in
+ * order, so all this has to do is keep the compiler from moving the reads over the writes.  The fences name the LDS
+ * address space only: a plain wavefront-scope fence also waits for vmcnt(0), i.e. for every outstanding global STORE
+ * of the wave to complete (~2-3 us under load), which is what the MT19937 paths did after every window fill. */
+#define UAM_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
+#define UAM_WAVE_LDS_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
+    __builtin_amdgcn_wave_barrier(); } while (0)
 #define UAM_MT_N 624
 #define UAM_MT_M 397
 #define UAM_MAX_BLOCK 512
@@ -309,33 +317,39 @@ __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
 typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32W;
 template <int U = 4>
 __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, const int gen, const int len, const int gl,
-                                              const int L, UAM_LDS_U32W win)
+                                              const int L, UAM_LDS_U32W win, unsigned long long* dbg = nullptr)
 {
+    /* BRANCH-FREE inside a chunk: with `if (k >= gen) { twist; store }` the value of word k reached the LDS write from
+     * two paths (loaded / computed), and at that merge the compiler waits for vmcnt(0) — on the computed path that is
+     * the completion of the STORE just issued, so a chunk paid U store round trips one after the other (~2.5 us each
+     * under load: 10 us per 224-word fill, measured).  Now every word's three loads are issued unconditionally (lanes
+     * past the end read a valid word and drop it), the new value is a select, and the stores of a chunk go out back to
+     * back behind ONE wait for its loads.  (A word that was already twisted is stored back unchanged.) */
     for (int i0 = 0; i0 < len; i0 += U * L) {
         uint32_t a[U], b[U], c[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int i = i0 + u * L + gl, k = pos + i;
-            a[u] = 0; b[u] = 0; c[u] = 0;
-            if (i < len) {
-                a[u] = key[k];
-                if (k >= gen) {
-                    int p1 = k + 1; if (p1 == UAM_MT_N) p1 = 0;
-                    int pm = k + UAM_MT_M; if (pm >= UAM_MT_N) pm -= UAM_MT_N;
-                    b[u] = key[p1]; c[u] = key[pm];
-                }
-            }
+            const int i = i0 + u * L + gl;
+            const int k = pos + (i < len ? i : 0);
+            int p1 = k + 1; if (p1 == UAM_MT_N) p1 = 0;
+            int pm = k + UAM_MT_M; if (pm >= UAM_MT_N) pm -= UAM_MT_N;
+            a[u] = key[k]; b[u] = key[p1]; c[u] = key[pm];
         }
+#if UAM_STAMP
+        if (dbg) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg[0] += __builtin_amdgcn_s_memtime() - t0;
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int i = i0 + u * L + gl, k = pos + i;
+            const uint32_t y = (a[u] & 0x80000000u) | (b[u] & 0x7fffffffu);
+            const uint32_t vt = c[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            const uint32_t v = k >= gen ? vt : a[u];
             if (i < len) {
-                uint32_t v = a[u];
-                if (k >= gen) {
-                    const uint32_t y = (a[u] & 0x80000000u) | (b[u] & 0x7fffffffu);
-                    v = c[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                    key[k] = v;
-                }
+                key[k] = v;
                 win[i] = mt_temper(v);
             }
         }
@@ -467,6 +481,136 @@ __device__ inline double mt_gauss(MtCtx& m)
     return f * x2;
 }
 
+/* ------------------------------------------------------------------ MT19937 in the step kernel: MtWin
+ * The step kernel draws ONLY from the env's LDS window, and the window is made long enough BEFORE a draw
+ * (mt_ensure), by the env's lane group together, inline: a draw itself is a plain LDS read.  No draw site carries a
+ * slow path and the kernel makes no calls: out-of-line slow paths (mt_refill_fn & co, still used by the reset
+ * kernel) cost the step kernel its registers — values live across a call sit in callee-saved registers, every other
+ * block of eight, which spread ~90 live values over 151 VGPRs = 3 waves/SIMD — and every call boundary drains the
+ * vector-memory counter, i.e. waits for the step's outstanding STORES.
+ * Every lane of the group holds the same MtWin (the group's draws are uniform). */
+/* words per lane in flight in the head's window fill / in a refill: registers of the step kernel (8 / 8 put it at 177
+ * VGPRs, 4 / 2 at 123 = 4 waves/SIMD) */
+#ifndef UAM_MT_OU
+#define UAM_MT_OU 4
+#endif
+#ifndef UAM_MT_RU
+#define UAM_MT_RU 2
+#endif
+#define UAM_RNG_MTWIN 3      /* Rng<> adaptor tag of this layer (not a uam_config rng_mode) */
+struct MtWin {
+    uint32_t* key;
+    int pos;                 /* cursor; >= 624 only while a window that ran over the end of the round is being consumed */
+    int gen;                 /* words [0, gen) of the cursor's round are twisted */
+    int gen_next;            /* words [0, gen_next) of the NEXT round are twisted too (a window ran over the end) */
+    int win_base, win_len;   /* the window holds the outputs of positions [win_base, win_base + win_len), numbered
+                              * straight on across the end of the round */
+    UAM_LDS_U32 win;
+    int has_gauss;
+    double gauss;
+    int cap, gl, L;          /* refill size (<= 8 L: one chunk, one memory round trip), lane in group, group width */
+};
+
+/* past the end of the round: the cursor's round becomes the one the window ran into */
+__device__ __forceinline__ void mt_win_normalize(MtWin& m)
+{
+    if (m.pos >= UAM_MT_N) { m.pos -= UAM_MT_N; m.win_base -= UAM_MT_N; m.gen = m.gen_next; m.gen_next = 0; }
+}
+
+/* Replace the window by the next `cap` words at the cursor (n <= cap words are needed NOW).  The window stops at the
+ * end of the round unless fewer than n words are left in it: then it runs on into the next round — new-round word k
+ * reads key[k], key[k+1] (still the old round's words, consumed long ago) and key[k+397], which is behind the cursor
+ * for any window shorter than 227 — and the caller consuming its n words right away is what guarantees that the
+ * cursor does cross (a window must never twist the next round while the cursor stays in this one: the lazy state
+ * (pos, gen) could not say so). */
+__device__ __forceinline__ void mt_win_refill(MtWin& m, const int n)
+{
+    mt_win_normalize(m);
+    const int len1 = min(m.cap, UAM_MT_N - m.pos);
+    int len2 = 0;
+    UAM_WAVE_LDS_RELEASE();
+    mt_twist_span<UAM_MT_RU>(m.key, m.pos, m.gen, len1, m.gl, m.L, (UAM_LDS_U32W)m.win);
+    m.gen = max(m.gen, m.pos + len1);
+    if (len1 < n) {
+        len2 = m.cap - len1;
+        mt_twist_span<UAM_MT_RU>(m.key, 0, m.gen_next, len2, m.gl, m.L, (UAM_LDS_U32W)m.win + len1);
+        m.gen_next = max(m.gen_next, len2);
+    }
+    UAM_WAVE_LDS_SYNC();
+    m.win_base = m.pos; m.win_len = len1 + len2;
+}
+__device__ __forceinline__ void mt_ensure(MtWin& m, const int n)
+{
+    if (m.pos - m.win_base + n > m.win_len) mt_win_refill(m, n);
+}
+/* two words -> rk_double; the caller has ensured them */
+__device__ __forceinline__ double mt_win_double(MtWin& m)
+{
+    const int wi = m.pos - m.win_base;
+    const uint32_t a = m.win[wi], b = m.win[wi + 1];
+    m.pos += 2;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * 0x1p-53;
+}
+/* legacy_gauss (numpy/random/src/legacy/legacy-distributions.c) */
+__device__ __forceinline__ double mt_win_gauss(MtWin& m)
+{
+    if (m.has_gauss) {
+        const double t = m.gauss;
+        m.gauss = 0.0;
+        m.has_gauss = 0;
+        return t;
+    }
+    double f, x1, x2, r2;
+    do {
+        mt_ensure(m, 4);
+        x1 = 2.0 * mt_win_double(m) - 1.0;
+        x2 = 2.0 * mt_win_double(m) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = __builtin_sqrt(-2.0 * uam_log(r2) / r2);
+    m.gauss = f * x1;
+    m.has_gauss = 1;
+    return f * x2;
+}
+/* the head of a step: the group loads the env's cursor and twists its first window (W <= 8 L words) */
+__device__ __forceinline__ void mt_win_open(const UamDev& s, const int e, const int gl, const int L, const int W, const int cap,
+                                            uint32_t* win, MtWin& m)
+{
+    m.key = s.mt_key + (size_t)e * UAM_MT_N;
+    m.pos = s.mt_pos[e]; m.gen = s.mt_gen[e];
+    m.has_gauss = s.mt_has_gauss[e]; m.gauss = s.mt_gauss[e];      /* (same address across the group: one broadcast load each) */
+    m.gen_next = 0;
+    if (m.pos >= UAM_MT_N) { m.pos = 0; m.gen = 0; }
+    const int len = min(W, UAM_MT_N - m.pos);
+    mt_twist_span<UAM_MT_OU>(m.key, m.pos, m.gen, len, gl, L, (UAM_LDS_U32W)win);
+    m.gen = max(m.gen, m.pos + len);
+    m.win = (UAM_LDS_U32)win; m.win_base = m.pos; m.win_len = len; m.cap = cap; m.gl = gl; m.L = L;
+    UAM_WAVE_LDS_SYNC();
+}
+/* the cursor through LDS between two stages of a step (it would otherwise be live across the whole sweep) */
+__device__ __forceinline__ void mt_win_park(MtHdr* h, const MtWin& m)
+{
+    h->pos = m.pos; h->gen = m.gen; h->has_gauss = m.has_gauss; h->gauss = m.gauss;
+    h->win_base = m.win_base; h->win_len = m.win_len; h->pad = m.gen_next;
+}
+__device__ __forceinline__ void mt_win_unpark(const UamDev& s, const int e, const MtHdr* h, const uint32_t* win, const int cap,
+                                              const int gl, const int L, MtWin& m)
+{
+    m.key = s.mt_key + (size_t)e * UAM_MT_N;
+    m.pos = h->pos; m.gen = h->gen; m.has_gauss = h->has_gauss; m.gauss = h->gauss;
+    m.win_base = h->win_base; m.win_len = h->win_len; m.gen_next = h->pad;
+    m.win = (UAM_LDS_U32)win; m.cap = cap; m.gl = gl; m.L = L;
+}
+/* the end of a step (lane 0 of the group) */
+__device__ __forceinline__ void mt_win_close(const UamDev& s, const int e, MtWin& m)
+{
+    if (m.gen_next > 0) mt_win_normalize(m);      /* (pos == 624 with nothing twisted ahead stays "wrap first") */
+    s.mt_pos[e] = m.pos;
+    s.mt_gen[e] = m.gen;
+    s.mt_has_gauss[e] = m.has_gauss;
+    s.mt_gauss[e] = m.gauss;
+}
+
 /* ------------------------------------------------------------------ RNG adaptors
  * quad(): the four uniforms of one spawn (x, y, speed, heading); two(): a redraw / the goal.
  * Philox draws one 4x32 block per call (32 random bits per quantity); MT19937 consumes the
@@ -540,6 +684,20 @@ template <> struct Rng<UAM_RNG_MT19937> {
         const MtDrawOut o = mt_draw_slow_fn(m.key, m.pos, m.gen, m.win_base, m.win_len, m.cap, m.gl, m.L, m.win, 2);
         u1 = o.u[0]; u2 = o.u[1];
         m.pos = o.pos; m.gen = o.gen; m.win_base = o.win_base; m.win_len = o.win_len;
+    }
+};
+
+template <> struct Rng<UAM_RNG_MTWIN> {
+    MtWin m;
+    __device__ __forceinline__ void quad(bool, uint32_t, uint32_t, double* u)
+    {
+        mt_ensure(m, 8);
+        u[0] = mt_win_double(m); u[1] = mt_win_double(m); u[2] = mt_win_double(m); u[3] = mt_win_double(m);
+    }
+    __device__ __forceinline__ void two(bool, uint32_t, uint32_t, uint32_t, double& u1, double& u2)
+    {
+        mt_ensure(m, 4);
+        u1 = mt_win_double(m); u2 = mt_win_double(m);
     }
 };
 
@@ -1093,6 +1251,38 @@ __device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int e
  * sequential, so the group walks i = 0..N-1 uniformly and the owner lane keeps
  * the result.  Stores the per-env fields (lane 0) and returns the obs tail.
  * ROS = SingleAircraftRandomEnv's random ownship start (needs fp64 trig here). */
+/* the tail of reset(): the per-env fields (lane 0 of the group) and the obs tail of the new episode */
+__device__ __forceinline__ void reset_finish(const UamParams& p, int env, int gl, uint32_t rc, float oxf, float oyf, double ohd,
+                                             double osp, double ovx, double ovy, double gx, double gy, float* tail,
+                                             float& rox, float& roy)
+{
+    /* every lane of the group has read reset_count; the group is one wave-resident unit */
+    __builtin_amdgcn_wave_barrier();
+    if (gl == 0) {
+        p.s.own_x[env] = oxf; p.s.own_y[env] = oyf;
+        p.s.own_h[env] = ohd; p.s.own_s[env] = osp;
+        p.s.own_vx[env] = ovx; p.s.own_vy[env] = ovy;
+        p.s.goal_x[env] = gx; p.s.goal_y[env] = gy;
+        p.s.no_conflict[env] = 0;
+        p.s.reset_count[env] = rc + 1u;
+    }
+    obs_tail(p, oxf, oyf, ovx, ovy, osp, ohd, gx, gy, tail);
+    rox = oxf; roy = oyf;
+}
+
+/* SingleAircraftRandomEnv.py:70-74 from the four uniforms of the ownship's draw */
+template <bool KC>
+__device__ __forceinline__ void reset_own_random(const UamParams& p, const double* u, double& ox, double& oy, double& osp,
+                                                 double& ohd, double& ovx, double& ovy)
+{
+    ox = 0.0 + p.c->W * u[0]; oy = 0.0 + p.c->H * u[1];
+    osp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
+    ohd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
+    double sn, cs;
+    sincos_sel<KC>(ohd, &sn, &cs);
+    ovx = (double)(float)(osp * cs); ovy = (double)(float)(osp * sn);
+}
+
 template <bool POS64, int RNG, bool SH, bool ROS, bool KC = false>
 __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_ok, Rng<RNG>& rng,
                                  Quad<POS64, SH>& q, float* tail, float& rox, float& roy)
@@ -1118,12 +1308,7 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     } else if constexpr (ROS) {   /* SingleAircraftRandomEnv.py:70-74 */
         double u[4];
         rng.quad(true, UAM_PH_RESET_OWN, 0, u);
-        ox = 0.0 + p.c->W * u[0]; oy = 0.0 + p.c->H * u[1];
-        osp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u[2];
-        ohd = 0.0 + (UAM_TWO_PI - 0.0) * u[3];
-        double sn, cs;
-        sincos_sel<KC>(ohd, &sn, &cs);
-        ovx = (double)(float)(osp * cs); ovy = (double)(float)(osp * sn);
+        reset_own_random<KC>(p, u, ox, oy, osp, ohd, ovx, ovy);
     }
     const float oxf = (float)ox, oyf = (float)oy;
     q.flags = 0;
@@ -1168,18 +1353,245 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
     double g1, g2;
     rng.two(true, UAM_PH_RESET_GOAL, 0, 0, g1, g2);   /* Goal(position=random_pos()), :91 */
     const double gx = p.c->goal_lo + p.c->goal_span_x * g1, gy = p.c->goal_lo + p.c->goal_span_y * g2;
-    /* every lane of the group has read reset_count above; the group is one wave-resident unit */
-    __builtin_amdgcn_wave_barrier();
-    if (gl == 0) {
-        p.s.own_x[env] = oxf; p.s.own_y[env] = oyf;
-        p.s.own_h[env] = ohd; p.s.own_s[env] = osp;
-        p.s.own_vx[env] = ovx; p.s.own_vy[env] = ovy;
-        p.s.goal_x[env] = gx; p.s.goal_y[env] = gy;
-        p.s.no_conflict[env] = 0;
-        p.s.reset_count[env] = rc + 1u;
+    reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy);
+}
+
+/* ------------------------------------------------------------------ MT19937: the in-step reset of a whole wave
+ * reset() draws 8 N + 4 words of the env's stream (+ 4 per rejected position) IN INTRUDER ORDER.  Walking the
+ * intruders one after the other (reset_env above) made the one wave of a launch that resets a 25-30 us straggler, and
+ * the slowest wave is what a launch takes.  Here instead
+ *   - the WHOLE WAVE twists the next <= 224 words of the resetting env's stream into a per-wave LDS buffer in one
+ *     memory round trip (any <= 227 consecutive words are independent; a span runs over the end of a round into the
+ *     next one when the reset is certain to consume past it), and
+ *   - the env's lane group draws its quads IN PARALLEL from the buffer: intruder i's words start at
+ *     8 i + 4 (rejections before i), so every lane guesses "no rejections before me", counts the words its four
+ *     intruders take from there, the group takes the exclusive prefix sum and lanes whose start moved count again —
+ *     lane 0 is right after one pass, every lane whose predecessors are right is right after the next: typically 1-2
+ *     passes.  Guesses are never too high, so a lane that runs off the buffer at its guess runs off it at its true
+ *     start too: the lanes before the first such lane are complete and draw once more for keeps, that lane itself
+ *     (its start is exact) keeps what fitted — down to "inside the rejection loop of slot j" — the cursor advances
+ *     by those words and the next segment resumes there.  The goal's four words belong to the last quad's lane.
+ * Every segment over a full buffer consumes at least four words, so this ends when the reference's own loop ends.
+ * Bit-identical to reset_env (the same arithmetic on the same words).
+ * Written for few code bytes and few registers, INLINE: rolled slot loops with the per-slot results in LDS (a lane's
+ * quad is in registers under compile-time indices only).  The first version of this, out of line over a scratch
+ * record, was as slow as the serial walk: every call boundary drains the vector-memory counter — the step's
+ * outstanding stores included — and unrolled fp64 slot code is 20 KB of instruction-cache misses for a path that one
+ * wave in a few hundred runs. */
+#define UAM_MT_BIG 224
+#define UAM_MT_SLOT_BYTES 40      /* x, y, speed, heading (float64), vx, vy (float32) of one new intruder */
+typedef __attribute__((address_space(3))) double* UAM_LDS_F64W;
+typedef __attribute__((address_space(3))) float* UAM_LDS_F32W;
+
+/* one lane's quad (slots j0 .. 3 of intruders 4 gl .. 4 gl + 3, then the goal if this is the last quad) drawn from
+ * the words at buf[off ...).  resume: slot j0 continues INSIDE its rejection loop (its first 8 words were taken by an
+ * earlier segment).  Returns words used | ovf << 16 | stop slot << 20 | stopped-in-rejection-loop << 24.
+ * COMMIT: keep the results (slot records in LDS, promotion flags, the goal); otherwise only count.
+ * The arithmetic is spawn_draw's and spawn_velocity's. */
+template <bool POS64, bool KC>
+__device__ __forceinline__ int mt_quad_from_buffer(const UamParams& p, const UAM_LDS_U32 buf, const int blen, const int off,
+                                                   const int gl, const int Q, const float oxf, const float oyf, const int j0,
+                                                   const bool resume, const bool COMMIT, UAM_LDS_F64W slots, uint32_t& promm,
+                                                   double& gx, double& gy)
+{
+    typedef typename PosT<POS64>::type P;
+    typedef Rng<UAM_RNG_MT19937> R;
+    int w = 0, jstop = 0;
+    bool ovf = false, stop_redraw = false;
+#pragma unroll 1
+    for (int j = j0; j < 4; j++) {
+        if (4 * gl + j < p.N && !ovf) {
+            P x = (P)0, y = (P)0;
+            bool prom = false, again = true;
+            const UAM_LDS_F64W rec = slots + 5 * j;
+            if (!(resume && j == j0)) {
+                const int o = off + w;
+                if (o + 8 > blen) { ovf = true; jstop = j; stop_redraw = false; }
+                else {
+                    const double u0 = R::dbl(buf[o], buf[o + 1]), u1 = R::dbl(buf[o + 2], buf[o + 3]);
+                    w += 8;
+                    const double fx = 0.0 + p.c->W * u0, fy = 0.0 + p.c->H * u1;
+                    x = (P)(float)fx; y = (P)(float)fy;
+                    if (COMMIT) {
+                        const double u2 = R::dbl(buf[o + 4], buf[o + 5]), u3 = R::dbl(buf[o + 6], buf[o + 7]);
+                        const double sp = p.c->min_speed + (p.c->max_speed - p.c->min_speed) * u2;
+                        const double hd = 0.0 + (UAM_TWO_PI - 0.0) * u3;
+                        float vx, vy;
+                        spawn_velocity<KC>(sp, hd, vx, vy);
+                        rec[2] = sp; rec[3] = hd;
+                        ((UAM_LDS_F32W)(rec + 4))[0] = vx; ((UAM_LDS_F32W)(rec + 4))[1] = vy;
+                    }
+                    again = too_close<POS64>(oxf, oyf, x, y, prom, p);
+                }
+            }
+            if (!ovf) {
+                while (again) {
+                    const int o2 = off + w;
+                    if (o2 + 4 > blen) { ovf = true; jstop = j; stop_redraw = true; break; }
+                    const double r1 = R::dbl(buf[o2], buf[o2 + 1]), r2 = R::dbl(buf[o2 + 2], buf[o2 + 3]);
+                    w += 4;
+                    const double fx = 0.0 + p.c->W * r1, fy = 0.0 + p.c->H * r2;
+                    if (POS64) { x = (P)fx; y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
+                    else { x = (P)(float)fx; y = (P)(float)fy; }
+                    again = too_close<POS64>(oxf, oyf, x, y, prom, p);
+                }
+                if (!ovf) {
+                    if (COMMIT) { rec[0] = (double)x; rec[1] = (double)y; promm |= (prom ? 1u : 0u) << (4 + j); }
+                }
+            }
+        }
     }
-    obs_tail(p, oxf, oyf, ovx, ovy, osp, ohd, gx, gy, tail);
-    rox = oxf; roy = oyf;
+    if (gl == Q - 1 && !ovf) {          /* Goal(position=random_pos()), :91 */
+        const int o = off + w;
+        if (o + 4 > blen) { ovf = true; jstop = 4; stop_redraw = false; }
+        else {
+            w += 4;
+            if (COMMIT) {
+                const double g1 = R::dbl(buf[o], buf[o + 1]), g2 = R::dbl(buf[o + 2], buf[o + 3]);
+                gx = p.c->goal_lo + p.c->goal_span_x * g1; gy = p.c->goal_lo + p.c->goal_span_y * g2;
+            }
+        }
+    }
+    return w | (ovf ? 1 << 16 : 0) | (jstop << 20) | (stop_redraw ? 1 << 24 : 0);
+}
+
+/* m = the group's stream (every lane of a group holds its own env's); lds = this wave's reset area:
+ * UAM_MT_BIG words, then 4 slot records for each lane of a group */
+template <bool POS64, bool SH, bool ROS, bool KC>
+__device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool need, const int env, const int gl, const int L,
+                                              const bool quad_ok, MtWin& m, Quad<POS64, SH>& q, float* tail, float& rox,
+                                              float& roy, uint32_t* lds, unsigned long long* st = nullptr)
+{
+#if UAM_STAMP
+    unsigned long long rs_last = __builtin_amdgcn_s_memtime();
+#define UAM_RSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st[i] += t_ - rs_last; rs_last = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define UAM_RSTAMP(i) do { } while (0)
+#endif
+    typedef typename PosT<POS64>::type P;
+    const int lane = threadIdx.x & 63;
+    const UAM_LDS_U32 big = (UAM_LDS_U32)lds;
+    const UAM_LDS_F64W slots = (UAM_LDS_F64W)(lds + UAM_MT_BIG) + 20 * gl;
+    const int Q = p.Q;
+    unsigned long long pend = __ballot(need && gl == 0);
+    while (pend) {                                   /* wave-uniform: one resetting env at a time */
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const bool mine = need && (lane - gl) == src;
+        if (mine) mt_win_normalize(m);
+        int pos = __shfl(m.pos, src), gen = __shfl(m.gen, src);
+        const int env_r = __shfl(env, src);
+        uint32_t* const key = p.s.mt_key + (size_t)env_r * UAM_MT_N;
+        const uint32_t rc = p.s.reset_count[env_r];
+        double ox = p.c->own_x0, oy = p.c->own_y0, osp = p.c->own_speed0, ohd = p.c->own_heading0;
+        double ovx = p.c->own_vx0, ovy = p.c->own_vy0;
+        float oxf = (float)ox, oyf = (float)oy;
+        bool own_done = !ROS;
+        int l0 = 0;                                  /* first lane (quad) of the group not completely drawn yet */
+        int j0 = 0; bool resume = false;             /* ... and where inside it the drawing resumes (that lane only) */
+        int need_lb = (ROS ? 8 : 0) + 8 * p.N + 4;   /* the rest of this reset consumes at least this many words */
+        int gen_next = 0;                            /* words of the NEXT round already twisted by a span that ran over */
+        uint32_t promm = 0;
+        double gx = 0.0, gy = 0.0;
+        for (;;) {                                   /* segments, wave-uniform */
+            if (pos >= UAM_MT_N) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
+            const int len1 = min(UAM_MT_BIG, UAM_MT_N - pos);
+            /* over the end of the round (see mt_win_refill) when the reset is certain to consume past it */
+            const int len2 = (len1 < UAM_MT_BIG && need_lb > len1) ? UAM_MT_BIG - len1 : 0;
+            UAM_WAVE_LDS_RELEASE();                 /* the previous segment's reads of the buffer are done */
+#pragma unroll 1
+            for (int part = 0; part < 2; part++) {      /* (one body for both parts: code bytes) */
+                const int plen = part ? len2 : len1;
+#if UAM_STAMP
+                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), st + 4);
+#else
+                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0));
+#endif
+            }
+            UAM_RSTAMP(3);
+            gen = max(gen, pos + len1);
+            gen_next = max(gen_next, len2);
+            UAM_WAVE_LDS_SYNC();
+            const int blen = len1 + len2;
+            UAM_RSTAMP(0);
+            int consumed = 0, finished = 0;
+            if (mine) {
+                int o0 = 0;
+                if (ROS && !own_done && blen >= 8) {
+                    double u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) u[i] = Rng<UAM_RNG_MT19937>::dbl(big[2 * i], big[2 * i + 1]);
+                    reset_own_random<KC>(p, u, ox, oy, osp, ohd, ovx, ovy);
+                    oxf = (float)ox; oyf = (float)oy;
+                    own_done = true; o0 = 8;
+                }
+                if (own_done) {
+                    const bool active = gl >= l0 && gl < Q;
+                    const int myj0 = gl == l0 ? j0 : 0;
+                    const bool myresume = gl == l0 && resume;
+                    int myoff = o0 + 32 * max(gl - l0, 0);
+                    int r = 0;
+                    bool commit = false;
+                    int first = Q;
+                    for (;;) {
+                        /* counting pass: how many words my quad (and, for the last quad, the goal) takes from myoff;
+                         * the last pass (offsets settled) runs the same code once more, for keeps: lanes [l0, first)
+                         * are complete, lane `first` (its start is exact) keeps what fitted */
+                        const bool doit = active && (!commit || gl <= first);
+                        if (doit) r = mt_quad_from_buffer<POS64, KC>(p, big, blen, myoff, gl, Q, oxf, oyf, myj0, myresume, commit, slots, promm, gx, gy);
+                        if (commit) break;
+                        if (!active) r = 0;
+                        const int w = r & 0xFFFF;
+                        int inc = w;                 /* exclusive prefix sum of the words used, over the lanes of the group */
+                        for (int d = 1; d < L; d <<= 1) {
+                            const int t = __shfl_up(inc, d, L);
+                            if (gl >= d) inc += t;
+                        }
+                        const int newoff = o0 + inc - w;
+                        const bool moved = active && newoff != myoff;
+                        myoff = newoff;
+                        if (!grp_or(moved ? 1u : 0u, L)) {
+                            const bool ovf = (r >> 16) & 1;
+                            first = (int)grp_min(active && ovf ? (uint32_t)gl : (uint32_t)Q, L);
+                            commit = true;
+                        }
+                    }
+                    UAM_RSTAMP(2);
+                    const int endoff = myoff + (r & 0xFFFF);
+                    consumed = (int)grp_max((active && gl <= first) ? (uint32_t)endoff : (uint32_t)o0, L);
+                    /* the resume point of lane `first`, known to the whole group */
+                    const uint32_t st = grp_max((active && gl == first) ? (uint32_t)(r >> 20) & 0x1Fu : 0u, L);
+                    l0 = first; j0 = (int)(st & 0xFu); resume = (st >> 4) & 1u;
+                    finished = first >= Q ? 1 : 0;
+                }
+            }
+            consumed = __shfl(consumed, src); finished = __shfl(finished, src);
+            pos += consumed;
+            need_lb = max(need_lb - consumed, 0);
+            if (finished) break;
+            if (consumed == 0) need_lb = max(need_lb, len1 + 1);      /* short buffer at the end of a round: run over it */
+        }
+        if (pos >= UAM_MT_N && gen_next > 0) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
+        if (mine) {
+            m.pos = pos; m.gen = gen; m.gen_next = 0; m.win_len = 0; m.win_base = 0;
+            /* my quad out of its slot records: compile-time slot indices from here on */
+            UAM_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (quad_ok && 4u * gl + j < (uint32_t)p.N) {
+                    const UAM_LDS_F64W rec = slots + 5 * j;
+                    q.x[j] = (P)rec[0]; q.y[j] = (P)rec[1];
+                    if (SH) { q.sp[SH ? j : 0] = rec[2]; q.hd[SH ? j : 0] = rec[3]; }
+                    q.vx[j] = ((UAM_LDS_F32W)(rec + 4))[0]; q.vy[j] = ((UAM_LDS_F32W)(rec + 4))[1];
+                }
+            }
+            q.flags = promm;                   /* new objects: conflict flags cleared */
+            /* the goal was drawn by the last quad's lane */
+            const int gsrc = (lane - gl) + (Q - 1);
+            gx = __shfl(gx, gsrc); gy = __shfl(gy, gsrc);
+            reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy);
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ built-in device-side policies
@@ -1473,7 +1885,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
 {
 #if UAM_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    unsigned long long stamp_local[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_local[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!PERSIST) stamp_acc = stamp_local;
 #endif
     Quad<POS64, SH> q_local;
@@ -1481,7 +1893,11 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     typedef typename PosT<POS64>::type P;
     constexpr bool RI = (MODE & UAM_MODE_RI) != 0, SHAPED = (MODE & UAM_MODE_SHAPED) != 0, KNN = (MODE & UAM_MODE_KNN) != 0;
     constexpr bool LEAN = UAM_LEAN(POS64, RNG, SH);
-    const int tid = threadIdx.x;
+    int tid_ = threadIdx.x;
+    /* MT19937 K-step kernel: everything derived from the thread index is recomputed per step instead of hoisted out
+     * of the K loop and held (or spilled) across the whole step; free in the single-step kernels */
+    if constexpr (RNG == UAM_RNG_MT19937) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int L = p.L;
     const int g = tid >> p.lshift, gl = tid & (L - 1);
     const int env = blockIdx.x * p.E + g;
@@ -1497,6 +1913,11 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     /* MT19937 only: per-env stream headers and windows behind the records and the obs staging */
     MtHdr* const mt_hdr_base = (MtHdr*)(lds_raw + (size_t)p.E * 48 + (p.obs_vec ? (size_t)p.E * p.D * 4 : 0));
     uint32_t* const mt_win_base = (uint32_t*)(mt_hdr_base + p.E);
+    /* refills of one chunk (UAM_MT_RU words per lane of the group in flight: one memory round trip), at least 16 words */
+    const int mt_cap = min(p.mt_win, max(UAM_MT_RU * L, 16));
+    /* this wave's reset area (reset_wave_mt): behind the windows, 8-byte aligned */
+    uint32_t* const mt_reset_lds = mt_win_base + (((size_t)p.E * p.mt_win + 1) & ~(size_t)1) +
+                                   (size_t)(tid >> 6) * (UAM_MT_BIG + (UAM_MT_SLOT_BYTES / 4) * 4 * L);
     if constexpr (PERSIST) {
         if (env_first >= p.B) return;
     } else if constexpr (RNG == UAM_RNG_MT19937) {
@@ -1514,20 +1935,14 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         if (env_ok) { own_load(pko, env, orr); own_fetch_inputs<RNG>(pko, env, k, oin); }
         quad_load<POS64, SH>(p, base, quad_ok, q);
         if (env_ok) {
-            MtCtx hm;
-            mt_window_fill<8>(p.s, env, gl, L, p.mt_first, mt_win_base + (size_t)g * p.mt_win, hm);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            hm.cap = min(p.mt_win, max(4 * L, 16));
-            oin.zh = mt_gauss(hm);   /* nothing else draws between the two normals */
-            oin.zs = mt_gauss(hm);
+            MtWin hm;
+            mt_win_open(p.s, env, gl, L, p.mt_first, mt_cap, mt_win_base + (size_t)g * p.mt_win, hm);
+            oin.zh = mt_win_gauss(hm);   /* nothing else draws between the two normals */
+            oin.zs = mt_win_gauss(hm);
             own_update<KC>(pko, *pko.c, orr, oin, lds_share + 3 * g, gl == 0);
-            if (gl == 0) { own_store(pko, env, orr); mt_store_lds(mt_hdr_base + g, hm); }
+            if (gl == 0) { own_store(pko, env, orr); mt_win_park(mt_hdr_base + g, hm); }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        UAM_WAVE_LDS_SYNC();
         if (env_first >= p.B) return;                /* whole wave past the batch end */
     } else {
         /* threads that run the ownship phase fetch their quad AFTER it, so the fp64 phase and the
@@ -1643,16 +2058,10 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     Rng<RNG> rng;
     bool vel_dirty = false;      /* some velocity / heading of my quad changed: respawn, reset, heading change */
     bool sp_dirty = false;       /* ... and a held speed with it: respawn or reset only */
-    bool mt_used = false;
+    Rng<UAM_RNG_MTWIN> wrng;     /* MT19937 instances: the env's stream, every lane of the group holds the same */
     if constexpr (RNG == UAM_RNG_MT19937) {
-        /* the cursor as the ownship thread left it; every lane of the group draws the same words from here on */
-        if (env_ok) {
-            rng.load_lds(p.s, env, mt_hdr_base + g, mt_win_base + (size_t)g * p.mt_win);
-            /* the group refills its window together; respawns take one chunk (one memory round trip) at a time,
-             * the reset raises this to the window's capacity */
-            rng.m.cap = min(p.mt_win, max(4 * L, 16)); rng.m.gl = gl; rng.m.L = L;
-            mt_used = true;
-        }
+        /* the cursor as the head of the step left it; every lane of the group draws the same words from here on */
+        if (env_ok) mt_win_unpark(p.s, env, mt_hdr_base + g, mt_win_base + (size_t)g * p.mt_win, mt_cap, gl, L, wrng.m);
     }
 
     /* ---- respawn */
@@ -1667,7 +2076,6 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             vel_dirty = true; sp_dirty = true;
         }
     } else if (env_ok) {
-        rng.gid = p.gid0 + (uint32_t)env; rng.c_step = PERSIST ? p.step_index + (uint32_t)k : uam_step_of(p, env, k); rng.c_reset = 0; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
         /* MT19937: respawns consume the env's stream in intruder order -> serve the
          * group's pending slots one at a time, smallest index first, group-uniformly */
         uint32_t pend = 0;                  /* my slots whose velocity is still to be computed */
@@ -1676,9 +2084,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             const uint32_t mine = resp ? 4u * gl + (uint32_t)(__ffs((int)resp) - 1) : 0xFFFFu;
             const uint32_t nxt = grp_min(mine, L);
             if (nxt == 0xFFFFu) break;
-            if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             P X, Y; bool prom; double sp, hd;
-            spawn_draw<POS64, RNG>(p, rng, nxt, false, ox, oy, X, Y, prom, sp, hd);
+            spawn_draw<POS64, UAM_RNG_MTWIN>(p, wrng, nxt, false, ox, oy, X, Y, prom, sp, hd);
             if (mine == nxt) {
                 const uint32_t jj = nxt & 3u;
                 resp &= ~(1u << jj);
@@ -1761,11 +2168,11 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
                 }
             }
         } else {
-            if (!mt_used) { rng.load(p.s, env); mt_used = true; }
             for (int i = 0; i < p.N; i++) {
-                const double pr = 0.0 + 1.0 * mt_double(rng.m);
+                mt_ensure(wrng.m, 4);
+                const double pr = 0.0 + 1.0 * mt_win_double(wrng.m);
                 if (pr < p.c->hc_prob) {
-                    const double ud = mt_double(rng.m);
+                    const double ud = mt_win_double(wrng.m);
                     if ((i >> 2) == gl) {
                         const double deg = -p.c->hc_max_deg + (p.c->hc_max_deg - (-p.c->hc_max_deg)) * ud;
 #pragma unroll
@@ -1821,9 +2228,11 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
 
     /* ---- VecEnv auto-reset: the obs of a done env is its reset obs (dummy_vec_env.py:52-55) */
     float kx = ox, ky = oy;      /* the ownship the k-nearest observation is measured from */
-    if (env_ok && done && p.auto_reset && !(UAM_ABLATE & 4)) {
-        if (RNG == UAM_RNG_MT19937 && !mt_used) { rng.load(p.s, env); mt_used = true; }
-        if constexpr (RNG == UAM_RNG_MT19937) rng.m.cap = rng.m.cap ? p.mt_win : 0;      /* 8 N words: full refills */
+    const bool reset_here = env_ok && done && p.auto_reset && !(UAM_ABLATE & 4);
+    if constexpr (RNG == UAM_RNG_MT19937) {
+        /* MT19937: the reset is the EPILOGUE of the step (below): here the cursor is parked again */
+        if (env_ok && gl == 0) mt_win_park(mt_hdr_base + g, wrng.m);
+    } else if (reset_here) {
         rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = PERSIST ? pk.step_index + (uint32_t)k : uam_step_of(pk, env, k);   /* (no graph-safe counter load in the looped kernel) */ rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
         reset_env<POS64, RNG, SH, ROS, KC>(pk, env, gl, quad_ok, rng, q, tail, kx, ky);
         vel_dirty = true; sp_dirty = true;
@@ -1835,7 +2244,6 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         }
         UAM_DRAIN_RARE_LOADS();
     }
-    if (RNG == UAM_RNG_MT19937 && mt_used && gl == 0) rng.store(p.s, env);
 
     UAM_STAMP_AT(7);
     /* ---- commit state + obs pack */
@@ -1869,6 +2277,47 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             }
         }
     }
+    if constexpr (RNG == UAM_RNG_MT19937 && !PERSIST) {
+        /* ---- MT19937: auto-reset as the step's epilogue.  Everything of the step has been stored — the done envs
+         * included, with the state and observation the step left — so nothing of the hot path is live any more and
+         * this rarely-run code does not cost the step kernel registers (inline at the reset's old place it put the
+         * kernel at 231 VGPRs).  The wave that has a done env waits for its stores, resets the env together
+         * (reset_wave_mt) and writes the new episode's state and observation over them. */
+        UAM_WAVE_LDS_SYNC();
+        MtWin em;
+        if (env_ok) mt_win_unpark(p.s, env, mt_hdr_base + g, mt_win_base + (size_t)g * p.mt_win, mt_cap, gl, L, em);
+        if (!(UAM_ABLATE & 64) && __ballot(reset_here)) {
+            UAM_STAMP_AT(9);
+            __builtin_amdgcn_s_waitcnt(0);                          /* this step's stores to the env's state and obs row are done */
+            UAM_STAMP_AT(10);
+            Quad<POS64, SH> qn;
+            float tn[8];
+            float rx = 0.f, ry = 0.f;
+#if UAM_STAMP
+            reset_wave_mt<POS64, SH, ROS, KC>(pk, reset_here, env, gl, L, quad_ok, em, qn, tn, rx, ry, mt_reset_lds, stamp_acc + 11);
+            stamp_last = __builtin_amdgcn_s_memtime();
+#else
+            reset_wave_mt<POS64, SH, ROS, KC>(pk, reset_here, env, gl, L, quad_ok, em, qn, tn, rx, ry, mt_reset_lds);
+#endif
+            if (reset_here) {
+                if (quad_ok) {
+                    quad_store_pos<POS64, SH>(pk, base, qn);
+                    quad_store_vel<POS64, SH>(pk, base, qn, true);
+                    pk.s.qf[base >> 2] = (uint8_t)qn.flags;
+                }
+                if (obs_k) {
+                    float* row = obs_k + (size_t)env * pk.D;
+                    if constexpr (KNN) {
+                        knn_row<POS64, SH>(pk, row, gl, L, true, quad_ok, qn, rx, ry, tn);
+                    } else {
+                        if (quad_ok) quad_obs<POS64, SH>(pk, row + (size_t)(4 * gl) * pk.obs_w, pk.obs_vec != 0, min(4, pk.N - 4 * gl), qn);
+                        store_tail(pk, row + (size_t)pk.N * pk.obs_w, pk.obs_vec != 0, gl, tn);
+                    }
+                }
+            }
+        }
+        if (env_ok && gl == 0) mt_win_close(p.s, env, em);
+    }
     if constexpr (!PERSIST) {
         /* graph-safe handles: the env's step counter advances here, after every path that reads it */
         if (p.env_step && env_ok && gl == 0) p.env_step[env] = p.env_step[env] + 1u;
@@ -1893,6 +2342,60 @@ __global__ void UAM_HEAVY_BOUNDS uam_sweep_heavy_kernel(const UamParams p)
     bool vd = false;
     int32_t ncf = 0;
     sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX), false>(p, lds_raw, 0, p.obs, q, vd, ncf);
+}
+
+/* the MT19937 instances, held at 128 VGPRs = 4 waves/SIMD: 65536 x 32 is 8192 waves, i.e. exactly two rounds of the
+ * chip's 4096 wave slots instead of 2.67 rounds of 3072 (the third mostly idle).  The hot path needs 123 (MtWin
+ * above: no calls); what spills is the reset epilogue. */
+#ifndef UAM_MT_WAVES_PER_EU
+#define UAM_MT_WAVES_PER_EU 4
+#endif
+template <bool POS64, int MODE, bool SH, bool ROS>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_MT_WAVES_PER_EU, 8)))
+uam_sweep_mt_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Quad<POS64, SH> q;
+    bool vd = false;
+    int32_t ncf = 0;
+    sweep_step<POS64, UAM_RNG_MT19937, MODE, SH, ROS, false, false>(p, lds_raw, 0, p.obs, q, vd, ncf);
+}
+
+/* K consecutive MT19937 steps in ONE launch (uam_rollout / uam_step_many on an action tape): the MT19937 step is
+ * wave-local — a wave only ever touches its own envs, no block barrier — so a wave simply runs its envs' K steps back
+ * to back, the state round-tripping through L2 like K separate launches would.  What this buys is not the K - 1
+ * launches: a SINGLE step's launch takes as long as its slowest wave, and one wave in a few hundred resets an env
+ * through ~6 KB of rarely-run code, every 64-byte line of it an instruction-cache miss (~1000 cycles under load: 20
+ * us for that wave, a third of the launch).  Over K steps those stragglers average out: a launch is as long as its
+ * waves' WORK.  Between two steps the wave waits for its own stores (workgroup-scope release/acquire: what lane 0 of
+ * a group stored, every lane of the group loads at the head of the next step). */
+template <bool POS64, int MODE, bool SH, bool ROS>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_MT_WAVES_PER_EU, 8)))
+uam_sweep_mt_many_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int K = p.many_K;
+    const size_t slot_elems = (size_t)p.B * (size_t)p.D;
+    int slot = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        float* obs_k = nullptr;
+        if (p.obs) {
+            if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
+            else if (k == K - 1) obs_k = p.obs;
+        }
+        Quad<POS64, SH> q;
+        bool vd = false;
+        int32_t ncf = 0;
+        /* every step reads its parameters afresh from the kernarg segment (scalar loads, cached): with the by-value copy
+         * the compiler hoists what it derives from them — array bases, env offsets, fp64 literals — out of the K loop
+         * and keeps it all in registers across the step (255 VGPRs without spilling, 568 B of scratch at 128) */
+        const UamParams* pp = (const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pp) :: "memory");
+        sweep_step<POS64, UAM_RNG_MT19937, MODE, SH, ROS, false, false>(*pp, lds_raw, k, obs_k, q, vd, ncf);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
 }
 
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
@@ -2141,6 +2644,7 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) uam_observe_kernel(const UamPar
     obs_emit<POS64, SH>(p, stage, env_first, env, g - wave_first_g, gl, env_ok, quad_ok, q, kx, ky, tail);
 }
 
+#ifndef UAM_TEMPLATES_ONLY      /* (uam_mt_kernels.hip: the plain kernels below belong to uamenv.hip's translation unit) */
 /* ownship noise drawn ahead for K consecutive steps (Philox): out[k*B + e] = (zh, zs) of step base+k.
  * Fully lane-parallel and off the step kernel's critical path; the values are exactly what the
  * step would have drawn itself (counter-based RNG). */
@@ -2231,5 +2735,6 @@ __global__ void __launch_bounds__(256) uam_her_input_reward_kernel(const UamHerP
     p.reward[i] = (float)rew;
     if (p.done) p.done[i] = term ? 1 : 0;
 }
+#endif /* UAM_TEMPLATES_ONLY */
 
 #endif /* UAM_DEVICE_H */

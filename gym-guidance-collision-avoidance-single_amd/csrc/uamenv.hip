@@ -364,13 +364,17 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     if (cfg->rng_mode == UAM_RNG_MT19937) {
         int w = 24 + (cfg->dynamics == UAM_DYN_RANDINTRUDER ? 2 * N + N / 4 : 0);
         e->mt_first = w > 224 ? 224 : w;
-        e->mt_win = e->mt_first < 96 ? 96 : e->mt_first;      /* a reset draws 8 N words: refills of 96 */
+        /* capacity: the first window or a refill (2 words per lane of the group, at least 16: uam_device.h mt_cap),
+         * whichever is longer; resets have their own per-wave buffer (reset_wave_mt) */
+        const int refill = 2 * L > 16 ? 2 * L : 16;
+        e->mt_win = e->mt_first > refill ? e->mt_first : refill;
         if (const char* mw = getenv("UAMENV_MT_WIN")) {        /* development override: "first" or "first,capacity" */
             int f = -1, c = -1;
             const int n = sscanf(mw, "%d,%d", &f, &c);
-            if (n >= 1 && f >= 0 && f <= 224) { e->mt_first = f; if (e->mt_win < f) e->mt_win = f; }
-            if (n == 2 && c >= e->mt_first && c <= 224) e->mt_win = c;
+            if (n >= 1 && f >= 0 && f <= 224) { e->mt_first = f; e->mt_win = f > refill ? f : refill; }
+            if (n == 2 && c >= e->mt_win && c <= 224) e->mt_win = c;
         }
+        e->mt_win = (e->mt_win + 1) & ~1;
     }
     e->Tm = T < 64 * L ? T : 64 * L;      /* the ownship wave has one lane per env of the block */
     e->Em = e->Tm / L;
@@ -534,10 +538,19 @@ extern "C" int uam_seed(uam_env* e, const uint64_t* seeds)
 
 /* ---- kernel dispatch over (precision, rng, dynamics, speed/heading held, random ownship start) ---- */
 /* the step kernel instance of a handle (every instance has the same signature) */
+/* the MT19937 instances live in uam_mt_kernels.hip (own compiler flags) */
+UamSweepFn uam_mt_kernel_for(bool pos64, bool ri, bool knn, bool shaped, bool hold_sh, bool ros, bool many);
+static UamSweepFn mt_kernel(const uam_env* e, bool many)
+{
+    return uam_mt_kernel_for(e->cfg.precision == UAM_POS_EXACT, e->cfg.dynamics == UAM_DYN_RANDINTRUDER,
+                             e->cfg.obs_mode == UAM_OBS_KNN5, e->cfg.shaped_reward != 0, e->hold_sh != 0,
+                             e->cfg.random_own_start != 0, many);
+}
+
 template <bool POS64, int RNG, int MODE, bool SH>
 static UamSweepFn step_fn_ros(const uam_env* e)
 {
-    if constexpr (POS64 || RNG == UAM_RNG_MT19937) {
+    if constexpr (POS64) {
         if (e->cfg.random_own_start) return uam_sweep_heavy_kernel<POS64, RNG, MODE, SH, true>;
         return uam_sweep_heavy_kernel<POS64, RNG, MODE, SH, false>;
     } else {
@@ -561,17 +574,25 @@ static UamSweepFn step_fn_t(const uam_env* e)
 static UamSweepFn step_fn(const uam_env* e)
 {
     const bool x = e->cfg.precision == UAM_POS_EXACT, mt = e->cfg.rng_mode == UAM_RNG_MT19937;
-    if (x && mt) return step_fn_t<true, UAM_RNG_MT19937>(e);
+    if (mt) return mt_kernel(e, false);
     if (x) return step_fn_t<true, UAM_RNG_PHILOX>(e);
-    if (mt) return step_fn_t<false, UAM_RNG_MT19937>(e);
     return step_fn_t<false, UAM_RNG_PHILOX>(e);
+}
+
+/* the K-steps-per-launch form of the MT19937 step kernel (same block shape and LDS as the single step) */
+static UamSweepFn mt_many_fn(const uam_env* e)
+{
+    if (e->cfg.rng_mode != UAM_RNG_MT19937 || e->shared_stream || e->ktiming) return nullptr;
+    if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return nullptr;
+    if (const char* f = getenv("UAMENV_MANY")) { if (!strcmp(f, "off")) return nullptr; }
+    return mt_kernel(e, true);
 }
 
 /* LDS of one step-kernel block: obs staging + the ownship records (+ MT19937: per-env stream header and window) */
 static inline size_t lds_step(const uam_env* e, bool staged)
 {
     return (staged ? (size_t)e->E * e->D * 4 : 0) + (size_t)e->E * 48 +
-           (e->cfg.rng_mode == UAM_RNG_MT19937 ? (size_t)e->E * (32 + 4 * (size_t)e->mt_win) : 0);
+           (e->cfg.rng_mode == UAM_RNG_MT19937 ? (size_t)e->E * 32 + 4 * (((size_t)e->E * e->mt_win + 1) & ~(size_t)1) + (size_t)((e->T + 63) / 64) * (224 * 4 + 160 * (size_t)e->L) : 0);
 }
 
 /* K steps in one launch (float32 / Philox instances only; everything else loops over single steps) */
@@ -699,9 +720,9 @@ static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
                 tsum += t; if (t > tmax) tmax = t;
             }
             fprintf(stderr, "[stamp step] waves=%d mean:", nw);
-            for (int i = 0; i < 9; i++) fprintf(stderr, " %.0f", sum[i] / nw);
+            for (int i = 0; i < UAM_NSTAMP; i++) fprintf(stderr, " %.0f", sum[i] / nw);
             fprintf(stderr, " | total %.0f\n[stamp step]        max:", tsum / nw);
-            for (int i = 0; i < 9; i++) fprintf(stderr, " %.0f", mx[i]);
+            for (int i = 0; i < UAM_NSTAMP; i++) fprintf(stderr, " %.0f", mx[i]);
             fprintf(stderr, " | total %.0f\n", tmax);
         }
         return;
@@ -875,6 +896,22 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
         /* slots after the first would lose the 16-byte alignment the staged obs path was chosen for */
         return fail(UAM_EINVAL, "obs slot size B*D*4 = %zu bytes is not a multiple of 16", slot_elems * 4);
     }
+    if (K > 1 && policy_kind < 0 && mt_many_fn(e)) {
+        /* MT19937: one launch, every wave runs its envs' K steps back to back (uam_sweep_mt_many_kernel) */
+        UamParams p;
+        fill_params(e, &p);
+        rc = check_obs_ptr(e, obs_out, &p);
+        if (rc) return rc;
+        p.actions = action_tape; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
+        p.many_K = K;
+        p.obs_slots = obs_slots;
+        p.act_step_words = (int32_t)(B * abytes / 4);
+        hipLaunchKernelGGL(mt_many_fn(e), dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), (hipStream_t)stream, p);
+        HIP_TRY(hipGetLastError());
+        e->step_index += (uint32_t)K;
+        if (e->timing) e->timed_launches++;
+        return UAM_OK;
+    }
     if (K > 1 && many_supported(e) && !(policy_kind >= 0 && many_flavour(e) != 1)) {
         /* one launch for all K steps (uam_sweep_many_kernel); the noise of exactly these steps is drawn first */
         hipStream_t st = (hipStream_t)stream;
@@ -946,7 +983,7 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
 extern "C" int32_t uam_steps_per_launch(const uam_env* e, int32_t K)
 {
     if (!e || K < 1) return 0;
-    return (K > 1 && many_supported(e)) ? K : 1;
+    return (K > 1 && (many_supported(e) || mt_many_fn(e))) ? K : 1;
 }
 
 extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,

@@ -13,7 +13,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     variant = rs.choice(["discrete9", "continuous", "continuous2", "mcts", "randintruder", "random_start", "her9", "her3"])
-    rng = rs.choice(["philox", "philox", "mt19937", "mt19937", "mt19937_shared"])
+    rng = os.environ.get("FUZZ_RNG") or rs.choice(["philox", "philox", "mt19937", "mt19937", "mt19937_shared"])
     prec = rs.choice(["f32", "exact"])
     N = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 32, 33, 64, 65, 100, 128, 200, 256]))
     B = int(rs.choice([1, 2, 3, 7, 31, 32, 33, 100, 257, 1000]))

@@ -14,7 +14,7 @@ budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 t0, n, bad = time.time(), 0, 0
 while time.time() - t0 < budget:
     variant = rs.choice(["discrete9", "continuous", "continuous2", "mcts", "randintruder", "random_start", "her9", "her3"])
-    rng = rs.choice(["philox", "philox", "philox", "mt19937"])
+    rng = os.environ.get("FUZZ_RNG") or rs.choice(["philox", "philox", "philox", "mt19937"])
     prec = rs.choice(["f32", "f32", "exact"])
     N = int(rs.choice([1, 2, 4, 5, 8, 9, 16, 31, 32, 33, 64, 100, 256]))
     if variant in ("her9", "her3") and N < 6:
