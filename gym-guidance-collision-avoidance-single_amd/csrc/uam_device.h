@@ -279,18 +279,6 @@ __device__ __forceinline__ void mt_load(const UamDev& s, int e, MtCtx& m)
     m.gauss = s.mt_gauss[e];
     m.win = (UAM_LDS_U32)0; m.win_base = 0; m.win_len = 0; m.cap = 0; m.gl = 0; m.L = 1;
 }
-__device__ __forceinline__ void mt_load_lds(const UamDev& s, int e, const MtHdr* h, const uint32_t* win, MtCtx& m)
-{
-    m.key = s.mt_key + (size_t)e * UAM_MT_N;
-    m.pos = h->pos; m.gen = h->gen; m.has_gauss = h->has_gauss; m.gauss = h->gauss;
-    m.win = (UAM_LDS_U32)win; m.win_base = h->win_base; m.win_len = h->win_len; m.cap = 0; m.gl = 0; m.L = 1;
-}
-__device__ __forceinline__ void mt_store_lds(MtHdr* h, const MtCtx& m)
-{
-    h->pos = m.pos; h->gen = m.gen; h->has_gauss = m.has_gauss; h->gauss = m.gauss;
-    h->win_base = m.win_base;
-    h->win_len = m.win_len;      /* 0 once the cursor has left the window's round */
-}
 __device__ __forceinline__ uint32_t mt_temper(uint32_t v)
 {
     v ^= (v >> 11);
@@ -415,24 +403,6 @@ __device__ __forceinline__ uint32_t mt_u32(MtCtx& m)
     const MtWordOut w = mt_word_fn(m.key, m.pos, m.gen);
     m.pos = w.pos; m.gen = w.gen;
     return w.v;
-}
-
-/* The env's lane group twists the first window of a step AHEAD, in parallel, and leaves it in LDS with the stream's
- * cursor: the ownship thread (another wave) draws its two normals from it, then the group carries on.  A draw costs an
- * LDS read instead of three dependent, uncoalesced global loads and a store per word.  The window stops at the end of
- * the round. */
-template <int U = 4>
-__device__ __forceinline__ void mt_window_fill(const UamDev& s, const int e, const int gl, const int L, const int W,
-                                               uint32_t* win, MtCtx& m)
-{
-    uint32_t* key = s.mt_key + (size_t)e * UAM_MT_N;
-    int pos = s.mt_pos[e], gen = s.mt_gen[e];
-    m.has_gauss = s.mt_has_gauss[e]; m.gauss = s.mt_gauss[e];      /* (same address across the group: one broadcast load each) */
-    if (pos >= UAM_MT_N) { pos = 0; gen = 0; }
-    const int len = min(W, UAM_MT_N - pos);
-    mt_twist_span<U>(key, pos, gen, len, gl, L, (UAM_LDS_U32W)win);
-    m.key = key; m.pos = pos; m.gen = max(gen, pos + len);
-    m.win = (UAM_LDS_U32)win; m.win_base = pos; m.win_len = len; m.cap = 0; m.gl = gl; m.L = L;
 }
 
 __device__ inline double mt_double(MtCtx& m)
@@ -650,7 +620,6 @@ template <> struct Rng<UAM_RNG_MT19937> {
     uint32_t gid, c_step, c_reset, k0, k1; /* unused */
     __device__ __forceinline__ void load(const UamDev& s, int e) { mt_load(s, e, m); }
     __device__ __forceinline__ void store(const UamDev& s, int e) { mt_store(s, e, m); }
-    __device__ __forceinline__ void load_lds(const UamDev& s, int e, const MtHdr* h, const uint32_t* win) { mt_load_lds(s, e, h, win, m); }
     /* When the next 8 (4) words are all in the window, take them with independent LDS reads issued together instead of
      * eight (four) read -> wait -> combine rounds: a reset draws 8 N words back to back */
     __device__ __forceinline__ static double dbl(uint32_t a, uint32_t b)
@@ -1778,9 +1747,9 @@ __device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, Own
  * written out so that this kernel's register allocation (63 VGPRs, 8 waves/SIMD) does not depend on the looped
  * kernel's needs; tests/test_gpu_rollout.py and the step_many tests hold the two forms bit-identical. */
 template <int RNG, bool KC = false>
-__device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, const int e, float4* sh, const int k = 0,
-                                            MtHdr* mt_hdr = nullptr, const uint32_t* mt_win = nullptr)
+__device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, const int e, float4* sh, const int k = 0)
 {
+    static_assert(RNG == UAM_RNG_PHILOX, "the MT19937 step runs its ownship phase in the lane group (sweep_step)");
     /* the cold configuration arrives BY VALUE (kernarg, scalar loads, no aliasing with the stores
      * below); every input is loaded up front so the thread pays one memory round trip, not five */
     float* __restrict__ own_x = p.s.own_x; float* __restrict__ own_y = p.s.own_y;
@@ -1796,18 +1765,8 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
     const uint32_t w0 = aw[i0], w1 = aw[is_pair ? i0 + 1 : i0];
     const int ai0 = (int)w0, ai1 = (int)w1;
     const float af = __uint_as_float(w0);
-    double zh, zs;
-    if constexpr (RNG == UAM_RNG_PHILOX) {
-        const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
-        zh = z.x; zs = z.y;
-    } else {
-        /* the stream cursor and the words twisted ahead by the env's lane group are in LDS (mt_window_fill) */
-        Rng<UAM_RNG_MT19937> rng;
-        rng.load_lds(p.s, e, mt_hdr, mt_win);
-        zh = mt_gauss(rng.m);   /* nothing else draws between the two normals */
-        zs = mt_gauss(rng.m);
-        mt_store_lds(mt_hdr, rng.m);
-    }
+    const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
+    const double zh = z.x, zs = z.y;
     double a0, a1;
     bool has_speed = true;
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
