@@ -253,8 +253,8 @@ struct MtCtx {
     uint32_t* key;
     int pos, gen, has_gauss;
     double gauss;
-    /* the step kernel's per-env window (LDS): TEMPERED outputs of words [win_base, win_base + win_len) of the
-     * current round, twisted ahead by the env's lane group (mt_window_fill); empty everywhere else */
+    /* (MtCtx is the stream as the RESET kernel and the one-lane contexts walk it; the step kernel uses MtWin below.)
+     * optional window in LDS: TEMPERED outputs of words [win_base, win_base + win_len) of the current round */
     UAM_LDS_U32 win;
     int win_base, win_len;
     /* cooperative refill (lane-group contexts only; cap = 0 elsewhere): when the window runs out, the group's L lanes
@@ -262,8 +262,8 @@ struct MtCtx {
     int cap, gl, L;
 };
 
-/* per-env header of the window in LDS (8 words): the stream cursor travels through it from the lane group (fill)
- * to the env's ownship thread (two normals) and back to the lane group (respawns, heading changes, reset) */
+/* per-env header of the step kernel's window in LDS (8 words): the stream cursor is parked here between the stages
+ * of a step (head, respawn / heading changes, reset epilogue) instead of being live across the sweep; pad = gen_next */
 struct MtHdr {
     int pos, gen, has_gauss, win_base;
     double gauss;
