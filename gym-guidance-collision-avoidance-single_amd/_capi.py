@@ -139,7 +139,7 @@ SYMBOLS = [
 def build(force=False):
     """Compile csrc/libuamenv_hip.so for gfx950 with hipcc (works without a GPU)."""
     # make knows every dependency (csrc/Makefile) and is a no-op when the library is up to date
-    subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j2"] + (["-B"] if force else []))
     return LIB_PATH
 
 

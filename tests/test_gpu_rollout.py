@@ -56,6 +56,50 @@ def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("variant,precision,B,N,K,R,one_launch", [
+    ("discrete9", "exact", 4096, 32, 40, 3, True),      # resets inside the launch (goal-seeking tape: episodes end)
+    ("continuous", "f32", 1000, 8, 9, 9, True),
+    ("randintruder", "exact", 600, 64, 6, 2, True),     # heading-change draws: the window is refilled several times a step
+    ("random_start", "exact", 300, 80, 30, 1, True),    # N = 80: a reset draws more than one round of the stream
+    ("her9", "exact", 500, 20, 5, 5, False),            # the HER variants loop over single-step launches
+])
+def test_mt19937_rollout_in_one_launch_equals_single_steps(uamenv, variant, precision, B, N, K, R, one_launch):
+    """uam_sweep_mt_many_kernel: every wave runs its envs' K steps back to back (the MT19937 step is wave-local).  Rewards,
+    dones, infos, the observation slots, the whole state and the position of every env's NumPy stream must equal K
+    separate uam_step launches, across episode ends inside the launch."""
+    import torch
+    kw = dict(variant=variant, rng="mt19937", precision=precision, seed=77)
+    a = uamenv.BatchedSingleAircraftEnv(B, N, **kw)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, **kw)
+    a.reset(); b.reset()
+    dev = a.device
+    assert (a.steps_per_launch(K) == K) == one_launch, "unexpected launch form"
+    ended = 0
+    for rep in range(3):
+        tape = torch.stack([a.policy_actions("goal" if (rep + k) % 4 else "random", seed=rep * 50 + k) for k in range(K)]).contiguous()
+        obs = torch.full((R, B, a.obs_dim), float("nan"), dtype=torch.float32, device=dev)
+        rew = torch.empty((K, B), dtype=torch.float32, device=dev)
+        done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        a.rollout_into(tape, rew, done, info, obs)
+        want = {}
+        for k in range(K):
+            o, r, d, i = b.step(tape[k])
+            assert torch.equal(rew[k], r) and torch.equal(done[k], d.view(torch.uint8)) and torch.equal(info[k], i.codes), (rep, k)
+            want[k % R] = o.clone()
+        for slot, o in want.items():
+            assert torch.equal(obs[slot], o), (rep, slot)
+        ended += int(done.sum())
+        ga, gb = a.get_state(), b.get_state()
+        pu.compare_states(ga, gb, "after rollout rep %d" % rep, hold_sh=variant == "randintruder")
+        for f in ("mt_pos", "mt_key"):
+            if f in ga:
+                assert (ga[f] == gb[f]).all(), f
+    if variant in ("discrete9", "random_start"):
+        assert ended > 0, "the tape must end episodes inside a launch"
+    a.close(); b.close()
+
+
 def test_rollout_rejects_bad_arguments(uamenv):
     import torch
     from uamenv import _capi as capi
