@@ -906,7 +906,27 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
         p.many_K = K;
         p.obs_slots = obs_slots;
         p.act_step_words = (int32_t)(B * abytes / 4);
+#if UAM_STAMP
+        {   /* development build: per-phase s_memtime of every wave's LAST step of the launch */
+            const int nw = grid_of(e) * (e->T / 64 > 0 ? e->T / 64 : 1);
+            static unsigned long long* dbuf = nullptr; static int dcap = 0;
+            if (dcap < nw) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void**)&dbuf, (size_t)nw * UAM_NSTAMP * 8); dcap = nw; }
+            (void)hipMemsetAsync(dbuf, 0, (size_t)nw * UAM_NSTAMP * 8, (hipStream_t)stream);
+            p.actions_out = dbuf;
+            hipLaunchKernelGGL(mt_many_fn(e), dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), (hipStream_t)stream, p);
+            std::vector<unsigned long long> h((size_t)nw * UAM_NSTAMP);
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[UAM_NSTAMP] = {0}, mx[UAM_NSTAMP] = {0};
+            for (int w = 0; w < nw; w++) for (int i = 0; i < UAM_NSTAMP; i++) { const double v = (double)h[(size_t)w * UAM_NSTAMP + i]; sum[i] += v; if (v > mx[i]) mx[i] = v; }
+            fprintf(stderr, "[stamp mt-many] K=%d waves=%d last step, mean:", K, nw);
+            double t = 0;
+            for (int i = 0; i < UAM_NSTAMP; i++) { fprintf(stderr, " %.0f", sum[i] / nw); t += sum[i] / nw; }
+            fprintf(stderr, " | total %.0f\n", t);
+        }
+#else
         hipLaunchKernelGGL(mt_many_fn(e), dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), (hipStream_t)stream, p);
+#endif
         HIP_TRY(hipGetLastError());
         e->step_index += (uint32_t)K;
         if (e->timing) e->timed_launches++;
