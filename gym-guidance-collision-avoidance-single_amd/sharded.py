@@ -80,7 +80,19 @@ class RolloutExchange:
             self._pending[c & 1] = self.dist.all_gather_into_tensor(self._gathered[c & 1], raw, async_op=True)
         else:
             outs = list(self._gathered[c & 1].view(self.world, -1).unbind(0)) if self.rank == 0 else None
-            self._pending[c & 1] = self.dist.gather(raw, gather_list=outs, dst=0, async_op=True)
+            try:
+                self._pending[c & 1] = self.dist.gather(raw, gather_list=outs, dst=0, async_op=True)
+            except (RuntimeError, NotImplementedError) as ex:
+                # a backend without gather (raised at call time, on every rank alike): the all-gather moves the same
+                # slabs — every rank receives them instead of rank 0 only
+                import torch
+                import warnings
+                warnings.warn("RolloutExchange: gather unavailable (%s); falling back to all_gather" % (ex,))
+                self.mode = "all_gather"
+                if self._gathered is None:
+                    self._gathered = [torch.zeros((self.world * self._KB * 5,), dtype=torch.uint8, device=raw.device)
+                                      for _ in range(2)]
+                self._pending[c & 1] = self.dist.all_gather_into_tensor(self._gathered[c & 1], raw, async_op=True)
         self.collectives += 1
 
     def drain(self):
