@@ -1843,6 +1843,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
                                            )
 {
 #if UAM_STAMP
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();      /* 100 MHz, the same clock on every CU */
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
     unsigned long long stamp_local[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!PERSIST) stamp_acc = stamp_local;
@@ -2286,6 +2287,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     if (!PERSIST && p.actions_out && (threadIdx.x & 63) == 0) {     /* single-step kernel: one record per wave */
         unsigned long long* dst = (unsigned long long*)p.actions_out + ((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * UAM_NSTAMP;
         for (int i = 0; i < UAM_NSTAMP; i++) dst[i] = stamp_acc[i];
+        dst[UAM_NSTAMP - 2] = stamp_rt0;                                  /* wave start / end in real time */
+        dst[UAM_NSTAMP - 1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 }

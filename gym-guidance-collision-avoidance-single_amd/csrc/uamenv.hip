@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #include "uam_device.h"
 
@@ -718,6 +719,22 @@ static void launch_step(uam_env* e, const UamParams& p, hipStream_t st)
                 double t = 0;
                 for (int i = 0; i < UAM_NSTAMP; i++) { const double v = (double)h[(size_t)w * UAM_NSTAMP + i]; sum[i] += v; if (v > mx[i]) mx[i] = v; t += v; }
                 tsum += t; if (t > tmax) tmax = t;
+            }
+            if (const char* dump = getenv("UAMENV_STAMP_DUMP")) {      /* raw per-wave records for offline analysis */
+                FILE* f = fopen(dump, "wb");
+                if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
+            {   /* when did the waves start and end (s_memrealtime, 10 ns ticks, relative to the first start)? */
+                std::vector<double> st(nw), en(nw);
+                double t0 = 1e300;
+                for (int w = 0; w < nw; w++) { st[w] = (double)h[(size_t)w * UAM_NSTAMP + UAM_NSTAMP - 2]; en[w] = (double)h[(size_t)w * UAM_NSTAMP + UAM_NSTAMP - 1]; if (st[w] < t0) t0 = st[w]; }
+                for (int w = 0; w < nw; w++) { st[w] = (st[w] - t0) * 0.01; en[w] = (en[w] - t0) * 0.01; }
+                std::vector<double> ss = st, ee = en;
+                std::sort(ss.begin(), ss.end()); std::sort(ee.begin(), ee.end());
+                fprintf(stderr, "[stamp step] wave starts (us): p50 %.2f p90 %.2f p99 %.2f max %.2f | ends: p1 %.2f p10 %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f | life p50 %.2f\n",
+                        ss[nw / 2], ss[nw * 9 / 10], ss[nw * 99 / 100], ss[nw - 1], ee[nw / 100], ee[nw / 10], ee[nw / 2], ee[nw * 9 / 10], ee[nw * 99 / 100], ee[nw - 1],
+                        ee[nw / 2] - ss[nw / 2]);
+                for (int w = 0; w < nw; w++) { h[(size_t)w * UAM_NSTAMP + UAM_NSTAMP - 2] = 0; h[(size_t)w * UAM_NSTAMP + UAM_NSTAMP - 1] = 0; }
             }
             fprintf(stderr, "[stamp step] waves=%d mean:", nw);
             for (int i = 0; i < UAM_NSTAMP; i++) fprintf(stderr, " %.0f", sum[i] / nw);
