@@ -355,8 +355,22 @@ def hbm_resident(ctx, args, variant):
             "note": "hipEvents around 5 x 64 queued launches, median; working set 1.1 GB state+obs, not cache-resident"}
 
 
+def ensure_built():
+    """The HIP library normally travels prebuilt; if it is missing or stale and a toolchain is here, build it ONCE, in
+    the process that starts the ranks (never in the ranks: N concurrent makes in one directory).  No torch, no GPU."""
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gym-guidance-collision-avoidance-single_amd", "csrc")
+    if os.environ.get("UAMENV_LIB"):
+        return
+    try:
+        subprocess.run(["make", "-C", csrc, "-s", "-j2"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+    except OSError:
+        pass            # no make here: uamenv raises a clear ImportError if the library really is missing
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        ensure_built()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
