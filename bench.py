@@ -388,11 +388,6 @@ def main():
         import torch.distributed as dist
         ctx.dist = dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # The step kernel fills every wave slot of the chip in ONE round (8 blocks per CU): each CU an RCCL kernel sits
-        # on while a slab is in flight pushes 8 step blocks into the launch's tail.  The exchange needs ~20 GB/s per
-        # peer (10.5 MB per 32-step chunk), so it gets few channels (each is one resident workgroup); overridable.
-        os.environ.setdefault("NCCL_NCHANNELS_PER_PEER", "2")
-        os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "16")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", ctx.local_rank))
         else:
