@@ -62,6 +62,7 @@ def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     ("randintruder", "exact", 600, 64, 6, 2, True),     # heading-change draws: the window is refilled several times a step
     ("random_start", "exact", 300, 80, 30, 1, True),    # N = 80: a reset draws more than one round of the stream
     ("her9", "exact", 500, 20, 5, 5, False),            # the HER variants loop over single-step launches
+    ("discrete9", "exact", 65536, 32, 8, 1, True),      # the benchmarked shape: two rounds of waves, resets in every launch
 ])
 def test_mt19937_rollout_in_one_launch_equals_single_steps(uamenv, variant, precision, B, N, K, R, one_launch):
     """uam_sweep_mt_many_kernel: every wave runs its envs' K steps back to back (the MT19937 step is wave-local).  Rewards,
