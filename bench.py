@@ -271,7 +271,9 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
            "value": float(sum(counts)) * steps / (median(reps_ms) * 1e-3),
            "ms_per_step": median(reps_ms) / steps,
            "steps_per_launch": (steps / launches[0]) if launches[0] else 0.0,
-           "kernel": ("uam_sweep_mt_many_kernel (one launch per chunk)" if args.rng == "mt19937" else "uam_sweep_many_kernel (one launch per chunk)") if looped
+           "kernel": ("uam_sweep_mt_many_kernel (one launch per chunk)" if args.rng == "mt19937" else
+                      "uam_sweep_heavy_many_kernel (one launch per chunk)" if args.precision == "exact" else
+                      "uam_sweep_many_kernel (one launch per chunk)") if looped
                      else ("uam_sweep_mt_kernel (one launch per step)" if args.rng == "mt19937" else "uam_sweep_kernel (one launch per step)"),
            "stream_span_ms_per_step": median(span_ms) / steps, "launches": launches[0],
            "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives,

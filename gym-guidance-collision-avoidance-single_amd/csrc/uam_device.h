@@ -2360,6 +2360,37 @@ uam_sweep_mt_many_kernel(const UamParams p)
     }
 }
 
+/* K consecutive steps in one launch for the float64-position Philox instances (uam_rollout on an action tape): a block
+ * only ever touches its own E envs, so it runs their K steps back to back — state through L2 as K launches would, a
+ * block barrier between steps (the ownship records in LDS are the block's) — without the per-launch ramp and tail
+ * (a step launch is its slowest wave).  The float32 instances have the register-resident looped kernel. */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
+uam_sweep_heavy_many_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int K = p.many_K;
+    const size_t slot_elems = (size_t)p.B * (size_t)p.D;
+    int slot = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        float* obs_k = nullptr;
+        if (p.obs) {
+            if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
+            else if (k == K - 1) obs_k = p.obs;
+        }
+        Quad<POS64, SH> q;
+        bool vd = false;
+        int32_t ncf = 0;
+        const UamParams* pp = (const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();      /* (see uam_sweep_mt_many_kernel) */
+        asm volatile("" : "+s"(pp) :: "memory");
+        sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX), false>(*pp, lds_raw, k, obs_k, q, vd, ncf);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
 __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
 {

@@ -580,6 +580,24 @@ static UamSweepFn step_fn(const uam_env* e)
     return step_fn_t<false, UAM_RNG_PHILOX>(e);
 }
 
+/* the K-steps-per-launch form of the float64-position Philox step kernel (block-local loop over the single step) */
+template <int MODE, bool SH>
+static UamSweepFn heavy_many_ros(const uam_env* e)
+{
+    if (e->cfg.random_own_start) return uam_sweep_heavy_many_kernel<true, UAM_RNG_PHILOX, MODE, SH, true>;
+    return uam_sweep_heavy_many_kernel<true, UAM_RNG_PHILOX, MODE, SH, false>;
+}
+static UamSweepFn heavy_many_fn(const uam_env* e)
+{
+    if (e->cfg.rng_mode != UAM_RNG_PHILOX || e->cfg.precision != UAM_POS_EXACT || e->ktiming || e->env_step) return nullptr;
+    if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return nullptr;
+    if (const char* f = getenv("UAMENV_MANY")) { if (!strcmp(f, "off")) return nullptr; }
+    if (e->cfg.obs_mode == UAM_OBS_KNN5 || e->cfg.shaped_reward) return nullptr;     /* (the HER variants loop over single steps) */
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) return heavy_many_ros<UAM_MODE_RI, true>(e);
+    if (e->hold_sh) return heavy_many_ros<0, true>(e);
+    return heavy_many_ros<0, false>(e);
+}
+
 /* the K-steps-per-launch form of the MT19937 step kernel (same block shape and LDS as the single step) */
 static UamSweepFn mt_many_fn(const uam_env* e)
 {
@@ -949,8 +967,10 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
         if (e->timing) e->timed_launches++;
         return UAM_OK;
     }
-    if (K > 1 && many_supported(e) && !(policy_kind >= 0 && many_flavour(e) != 1)) {
-        /* one launch for all K steps (uam_sweep_many_kernel); the noise of exactly these steps is drawn first */
+    const bool heavy_many = K > 1 && policy_kind < 0 && heavy_many_fn(e) != nullptr;
+    if (heavy_many || (K > 1 && many_supported(e) && !(policy_kind >= 0 && many_flavour(e) != 1))) {
+        /* one launch for all K steps (uam_sweep_many_kernel; float64 positions: uam_sweep_heavy_many_kernel); the noise
+         * of exactly these steps is drawn first */
         hipStream_t st = (hipStream_t)stream;
         if (e->noise_many_cap < K) {
             /* rare: grow the buffer.  Synchronous on purpose — the old buffer may still be read by a launch in
@@ -987,7 +1007,8 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
             p.actions_out = const_cast<void*>(action_tape);
             e->policy_calls += (uint32_t)K;
         }
-        launch_many(e, p, st);
+        if (heavy_many) hipLaunchKernelGGL(heavy_many_fn(e), dim3(grid_of(e)), dim3(e->T), lds_step(e, p.obs_vec != 0), st, p);
+        else launch_many(e, p, st);
         HIP_TRY(hipGetLastError());
         e->step_index += (uint32_t)K;
         if (e->timing) e->timed_launches++;
@@ -1020,7 +1041,7 @@ static int step_many_impl(uam_env* e, int32_t K, const void* action_tape, float*
 extern "C" int32_t uam_steps_per_launch(const uam_env* e, int32_t K)
 {
     if (!e || K < 1) return 0;
-    return (K > 1 && (many_supported(e) || mt_many_fn(e))) ? K : 1;
+    return (K > 1 && (many_supported(e) || mt_many_fn(e) || heavy_many_fn(e))) ? K : 1;
 }
 
 extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,

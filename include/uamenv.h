@@ -147,9 +147,10 @@ typedef struct uam_config {
                                   whole grid is resident in one round (small batches, shards of a partitioned batch) and as
                                   K queued single-step launches otherwise; UAM_FUSE_ALWAYS (1) uses the looped kernel
                                   whenever the handle's modes have one (float32 + Philox), in as many rounds as the grid
-                                  needs; UAM_FUSE_NEVER (2).  MT19937 handles (per-env streams, not the HER variants) run
-                                  a chunk as ONE launch under AUTO and ALWAYS at any batch size: their step is wave-local,
-                                  every wave runs its envs' K steps back to back.  Results are identical in every case. */
+                                  needs; UAM_FUSE_NEVER (2).  MT19937 handles (per-env streams) and float64-position
+                                  Philox handles (neither for the HER variants) run a chunk as ONE launch under AUTO and
+                                  ALWAYS at any batch size: a wave (MT19937) or a block (float64 positions) runs its
+                                  envs' K steps back to back.  Results are identical in every case. */
     int32_t graph_safe;        /* 1: uam_step / uam_policy / uam_observe only enqueue kernels whose arguments never change
                                   from one call to the next — the step counter of the Philox draws lives in device memory
                                   (one counter per env, advanced by the step itself) and the ownship noise is drawn by a

@@ -101,6 +101,39 @@ def test_mt19937_rollout_in_one_launch_equals_single_steps(uamenv, variant, prec
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("variant,B,N,K,R", [
+    ("discrete9", 4096, 32, 24, 2),
+    ("randintruder", 600, 64, 6, 6),
+    ("random_start", 300, 80, 12, 1),
+    ("discrete9", 65536, 32, 6, 1),
+])
+def test_exact_philox_rollout_in_one_launch_equals_single_steps(uamenv, variant, B, N, K, R):
+    """uam_sweep_heavy_many_kernel (float64 positions, Philox): every block runs its envs' K steps back to back."""
+    import torch
+    kw = dict(variant=variant, rng="philox", precision="exact", seed=78)
+    a = uamenv.BatchedSingleAircraftEnv(B, N, **kw)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, **kw)
+    a.reset(); b.reset()
+    dev = a.device
+    assert a.steps_per_launch(K) == K
+    for rep in range(3):
+        tape = torch.stack([a.policy_actions("goal" if (rep + k) % 4 else "random", seed=rep * 50 + k) for k in range(K)]).contiguous()
+        obs = torch.full((R, B, a.obs_dim), float("nan"), dtype=torch.float32, device=dev)
+        rew = torch.empty((K, B), dtype=torch.float32, device=dev)
+        done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+        a.rollout_into(tape, rew, done, info, obs)
+        want = {}
+        for k in range(K):
+            o, r, d, i = b.step(tape[k])
+            assert torch.equal(rew[k], r) and torch.equal(done[k], d.view(torch.uint8)) and torch.equal(info[k], i.codes), (rep, k)
+            want[k % R] = o.clone()
+        for slot, o in want.items():
+            assert torch.equal(obs[slot], o), (rep, slot)
+        pu.compare_states(a.get_state(), b.get_state(), "after rollout rep %d" % rep, hold_sh=variant == "randintruder")
+    a.close(); b.close()
+
+
 def test_rollout_rejects_bad_arguments(uamenv):
     import torch
     from uamenv import _capi as capi
