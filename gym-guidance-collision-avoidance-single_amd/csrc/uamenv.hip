@@ -673,9 +673,11 @@ static int many_flavour(const uam_env* e)
     if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return 0;
     if (grid_many(e, 1) <= e->many_resident_blocks) return 1;
     if (e->many4_resident_blocks > 0 && grid_many(e, 2) <= e->many4_resident_blocks) return 2;
-    /* several rounds of blocks: register-resident state still saves the per-step state traffic (measured 1.25-1.4x
-     * over single-step launches at 65536 ... 1 M envs x 32), but the launch is no longer a latency-regime one */
-    if (e->cfg.fuse_rollout == UAM_FUSE_ALWAYS) return many4_fn(e) ? 2 : 1;
+    /* several rounds of blocks: register-resident state still saves the per-step state traffic and the per-launch
+     * ramp and tail (measured 1.25-1.46x over single-step launches at 65536 ... 1 M envs x 32) for the instances that
+     * have the flavour without ownship wave; the others only on request */
+    if (many4_fn(e)) return 2;
+    if (e->cfg.fuse_rollout == UAM_FUSE_ALWAYS) return 1;
     return 0;
 }
 

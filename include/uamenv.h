@@ -143,11 +143,12 @@ typedef struct uam_config {
     double goal_margin;        /* goal drawn in [m, W-m] x [m, H-m]: 100 in random_goal_pos (:349-353), 0 elsewhere */
     int32_t shaped_reward;     /* 1: the non-terminal step reward gets + (conflict_coeff * d - 0.1) when the nearest swept
                                   intruder is closer than 3 * minimum_separation (:225-232) */
-    int32_t fuse_rollout;      /* uam_step_many / uam_rollout: UAM_FUSE_AUTO (0) runs a chunk as ONE looped launch while the
-                                  whole grid is resident in one round (small batches, shards of a partitioned batch) and as
-                                  K queued single-step launches otherwise; UAM_FUSE_ALWAYS (1) uses the looped kernel
+    int32_t fuse_rollout;      /* uam_step_many / uam_rollout: UAM_FUSE_AUTO (0) runs a chunk as ONE looped launch where
+                                  that is measured faster than K queued single-step launches — while the whole grid is
+                                  resident in one round (small batches, shards of a partitioned batch), and at any size
+                                  for the plain step (discrete-9 / continuous); UAM_FUSE_ALWAYS (1) uses the looped kernel
                                   whenever the handle's modes have one (float32 + Philox), in as many rounds as the grid
-                                  needs; UAM_FUSE_NEVER (2).  MT19937 handles (per-env streams) and float64-position
+                                  needs; UAM_FUSE_NEVER (2): one launch per step.  MT19937 handles (per-env streams) and float64-position
                                   Philox handles (neither for the HER variants) run a chunk as ONE launch under AUTO and
                                   ALWAYS at any batch size: a wave (MT19937) or a block (float64 positions) runs its
                                   envs' K steps back to back.  Results are identical in every case. */

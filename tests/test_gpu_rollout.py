@@ -26,7 +26,8 @@ def uamenv():
     ("randintruder", 512, 64, 5, 1, True),     # one buffer overwritten every step
     ("her9", 700, 20, 9, 4, True),
     ("discrete9", 32768, 32, 5, 3, True),      # every wave slot taken by sweeping waves: the flavour without ownship wave
-    ("discrete9", 65536, 32, 4, 2, False),     # grid larger than one resident round: K queued single-step launches
+    ("discrete9", 65536, 32, 4, 2, True),      # grid larger than one resident round: the looped kernel in two rounds
+    ("randintruder", 65536, 16, 3, 1, False),  # ... for the plain step only: this one queues K single-step launches
     ("discrete9", 300, 5, 6, 6, True),         # D = 28: 16-byte aligned rows only every 4th env
 ])
 def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):

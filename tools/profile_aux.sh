@@ -4,7 +4,7 @@
 #   strong_shard_shapes.jsonl          BASELINE config 4's per-rank shapes on one GPU (looped kernel, no exchange)
 #   closed_loop.jsonl                  tools/bench_closed_loop.py: eager / HIP graph / in-kernel policy
 #   bench_n2_gloo_same_device.json     2-rank rehearsal of bench.py's own exchange path on one GPU
-#   bench_mt19937_exact.jsonl          MT19937 / exact mode: rollout chunks (K-step launches), then single-step launches
+#   bench_mt19937_exact.jsonl          exact-position modes (MT19937, then Philox): `value` = single-step launches, `fused_rollout` = chunks
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r02}
@@ -23,7 +23,7 @@ echo "closed loop done"
 timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --same-device --no-cpu-baseline 2> $OUT/n2.err | grep '^{' > $OUT/bench_n2_gloo_same_device.json
 echo "n2 rehearsal done"
 : > $OUT/bench_mt19937_exact.jsonl
-python3 bench.py --rng mt19937 --precision exact --steps 640 --warmup 128 --reps 3 --no-secondary --no-cpu-baseline 2>> $OUT/mt.err | grep '^{' >> $OUT/bench_mt19937_exact.jsonl
-UAMENV_MANY=off python3 bench.py --rng mt19937 --precision exact --steps 640 --warmup 128 --reps 3 --no-secondary --no-cpu-baseline 2>> $OUT/mt.err | grep '^{' >> $OUT/bench_mt19937_exact.jsonl
-python3 bench.py --precision exact --steps 640 --warmup 128 --reps 3 --no-secondary --no-cpu-baseline 2>> $OUT/mt.err | grep '^{' >> $OUT/bench_mt19937_exact.jsonl
+# value = one launch per step, fused_rollout = one launch per chunk, in the same line; MT19937 first, then Philox
+python3 bench.py --rng mt19937 --precision exact --steps 640 --warmup 128 --reps 3 --no-cpu-baseline 2>> $OUT/mt.err | grep '^{' >> $OUT/bench_mt19937_exact.jsonl
+python3 bench.py --precision exact --steps 640 --warmup 128 --reps 3 --no-cpu-baseline 2>> $OUT/mt.err | grep '^{' >> $OUT/bench_mt19937_exact.jsonl
 echo "mt done"
