@@ -713,7 +713,7 @@ def test_config4_continuous_65536x32_sharded_8_ways_matches_oracle(uamenv, oracl
     import torch
     from uamenv.sharded import shard_bounds
     B, N, K, W = 65536, 32, 10, 8
-    whole = uamenv.BatchedSingleAircraftEnv(B, N, variant="continuous", seed=404)
+    whole = uamenv.BatchedSingleAircraftEnv(B, N, variant="continuous", seed=404, fuse_rollout="never")    # launch by launch
     ocfg = pu.oracle_cfg_from(oracle, whole.cfg)
     orc = oracle.OracleBatch(ocfg, oracle.MATH_PORTABLE, threads=16)
     spans = [shard_bounds(B, W, r) for r in range(W)]
