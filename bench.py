@@ -74,9 +74,17 @@ def parse_args(argv=None):
     ap.add_argument("--rng", default="philox", choices=["philox", "mt19937"])
     ap.add_argument("--precision", default="f32", choices=["f32", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=6.0,
+                    help="length of the closing sustained pass of the primary workload (0 = skip; profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second workload and the 1 M-env pass")
     ap.add_argument("--backend", default="nccl", help="rehearsal only: gloo lets 2 ranks share one GPU box")
     ap.add_argument("--same-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--dump-exchange", default=None, metavar="NPZ",
+                    help="rehearsal only: after the measurements, step ONE partitioned batch for two chunks from a tape "
+                         "every rank derives from the same seed and let rank 0 save what its collectives gathered "
+                         "(tests compare it byte for byte with one unsharded handle)")
+    ap.add_argument("--no-build", action="store_true", help="do not run make first (profiling runs: the profiled "
+                    "process must not spawn children)")
     return ap.parse_args(argv)
 
 
@@ -89,6 +97,9 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # RCCL maps its peers' buffers through HIP IPC handles.  This image's host driver supports dmabuf IPC only: with the
+    # legacy mode left on, hipIpcGetMemHandle fails with "invalid argument" and the communicator never comes up.  The
+    # image exports the variable already; it is set here too so that a caller's scrubbed environment cannot lose it.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
@@ -116,12 +127,15 @@ def cpu_baseline(B, N, nthreads):
         env.close()
         return B * steps / el, steps
 
-    v_all, s_all = rate(nthreads, 8.0)
-    v_one, s_one = rate(1, 6.0)
-    return {"value": v_all, "unit": "env-steps/s", "cores": nthreads, "kind": "port",
-            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, %d steps on %d threads "
-                      "(+ %d steps on 1 thread), random actions, float64 obs written" % (B, N, s_all, nthreads, s_one),
-            "single_thread": v_one, "nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)),
+    aff = len(os.sched_getaffinity(0))
+    v_all, s_all = rate(aff, 6.0)                      # every core this process may run on
+    v_16, s_16 = (rate(nthreads, 5.0) if nthreads < aff else (v_all, s_all))
+    v_one, s_one = rate(1, 5.0)
+    return {"value": v_all, "unit": "env-steps/s", "cores": aff, "kind": "port",
+            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, random actions, float64 obs written: "
+                      "%d steps on all %d threads of the affinity mask (`value`), %d steps on %d threads, %d steps on 1 thread; "
+                      "run BEFORE the GPU phases" % (B, N, s_all, aff, s_16, nthreads, s_one),
+            "threads_%d" % nthreads: v_16, "single_thread": v_one, "nproc": os.cpu_count(), "affinity": aff,
             "reference_python": REF_PYTHON}
 
 
@@ -135,7 +149,7 @@ def median(xs):
     return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
 
 
-def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fuse="auto"):
+def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fuse="auto", sustain_s=0.0):
     """One workload on this rank's shard: spin-up, `warmup` untimed steps, then `reps` repetitions of exactly `steps`
     steps, each bracketed by barrier + synchronize; max over ranks per repetition."""
     torch, dist = ctx.torch, ctx.dist
@@ -266,7 +280,16 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
         timed_region(n_long, warmup)
         ms, _, _ = timed_region(n_long, warmup)
         steady = {"steps": n_long, "ms_per_step": ms / n_long, "value": float(sum(counts)) * n_long / (ms * 1e-3)}
-    out = {"scaling": scaling, "variant": variant, "envs_per_gpu": B, "envs_total": sum(counts), "chunk": K,
+    sustained = None
+    if sustain_s > 0 and args.policy == "random":
+        # seconds, not milliseconds, of the same protocol: the rate the path holds once clocks and temperatures have
+        # settled (and a GPU phase long enough for an external utilisation sampler to see)
+        per_step_ms = (steady["ms_per_step"] if steady else median(reps_ms) / steps)
+        n_sus = max(K, int(sustain_s * 1e3 / per_step_ms) // K * K)
+        ms, _, _ = timed_region(n_sus, warmup)
+        sustained = {"seconds": ms * 1e-3, "steps": n_sus, "ms_per_step": ms / n_sus,
+                     "value": float(sum(counts)) * n_sus / (ms * 1e-3)}
+    out = {"scaling": scaling, "variant": variant, "envs_per_gpu": B, "envs_total": sum(counts), "chunk": K, "sustained": sustained,
            "obs_slots": R, "reps_ms": reps_ms, "median_ms": median(reps_ms),
            "value": float(sum(counts)) * steps / (median(reps_ms) * 1e-3),
            "ms_per_step": median(reps_ms) / steps,
@@ -325,8 +348,8 @@ def hbm_resident(ctx, args, variant):
     gen = torch.Generator(device=dev)
     gen.manual_seed(7)
     am = env.cfg.action_mode
-    if am == 2:
-        tape = torch.rand((8, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
+    if am in (2, 4):      # ACT_CONTINUOUS1 / ACT_CONTINUOUS2 (float32, one or two words per env)
+        tape = torch.rand((8, B, 2) if am == 4 else (8, B), dtype=torch.float32, device=dev, generator=gen) * 2 - 1
     else:
         tape = torch.randint(0, 9 if am == 0 else 3, (8, B, 2) if am == 1 else (8, B), dtype=torch.int32, device=dev,
                              generator=gen)
@@ -379,6 +402,42 @@ def hbm_resident(ctx, args, variant):
     return out
 
 
+def exchange_dump(ctx, args, path):
+    """The exchange path with known inputs: the strong partition of ONE continuous batch, two chunks of 16 steps from a
+    tape that is a function of the global env index only, each chunk's reward/done slab through the rank's
+    RolloutExchange exactly as measure() drives it.  Rank 0 saves the gathered [2 * 16, B_total] rewards and dones."""
+    import numpy as np
+    torch, dist = ctx.torch, ctx.dist
+    import uamenv
+    from uamenv.sharded import RolloutExchange, shard_bounds
+    Btot, N, K = args.batch, args.intruders, 16
+    spans = [shard_bounds(Btot, ctx.world, r) for r in range(ctx.world)]
+    first, B = spans[ctx.rank]
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="continuous", seed=0, auto_reset=True, device=ctx.local_rank,
+                                          env_id_offset=first)
+    dev = env.device
+    env.reset()
+    tape_all = np.random.RandomState(1234).uniform(-1.0, 1.0, size=(2 * K, Btot)).astype(np.float32)
+    tape = torch.from_numpy(np.ascontiguousarray(tape_all[:, first:first + B])).to(dev)
+    info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    mode = args.exchange if args.exchange != "none" else "gather"
+    ex = RolloutExchange(dist, K, [c for _, c in spans], ctx.rank, dev, mode=mode, force=dist is not None)
+    for c in (0, 1):
+        ex.begin(c)
+        rew, done = ex.slab(c)
+        env.rollout_into(tape[c * K:(c + 1) * K].contiguous(), rew, done, info)
+        ex.exchange(c)
+    ex.drain()
+    torch.cuda.synchronize()
+    if ctx.rank == 0:
+        r0, d0 = ex.gathered(0)
+        r1, d1 = ex.gathered(1)
+        np.savez(path, rew=torch.cat([r0, r1]).cpu().numpy(), done=torch.cat([d0, d1]).cpu().numpy(), tape=tape_all,
+                 intruders=N, world=ctx.world, mode=mode, collectives=ex.collectives,
+                 steps_per_launch=int(env.steps_per_launch(K)))
+    env.close()
+
+
 def ensure_built():
     """The HIP library normally travels prebuilt; if it is missing or stale and a toolchain is here, build it ONCE, in
     the process that starts the ranks (never in the ranks: N concurrent makes in one directory).  No torch, no GPU."""
@@ -386,17 +445,28 @@ def ensure_built():
     if os.environ.get("UAMENV_LIB"):
         return
     try:
-        subprocess.run(["make", "-C", csrc, "-s", "-j2"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        r = subprocess.run(["make", "-C", csrc, "-s", "-j2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False)
+        if r.returncode != 0:       # never benchmark a stale library in silence
+            sys.stderr.write("bench.py: `make -C %s` failed (rc %d); the library on disk, if any, is STALE:\n%s\n"
+                             % (csrc, r.returncode, r.stdout.decode("utf-8", "replace")[-2000:]))
     except OSError:
         pass            # no make here: uamenv raises a clear ImportError if the library really is missing
 
 
 def main():
     args = parse_args()
-    if "WORLD_SIZE" not in os.environ:
+    if "WORLD_SIZE" not in os.environ and not args.no_build:
         ensure_built()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        # FIRST, before this process touches the GPU: the CPU oracle on the host cores (the GPU phases then close the run)
+        try:
+            cpu = cpu_baseline(args.batch, args.intruders, min(16, len(os.sched_getaffinity(0))))
+        except Exception as ex:   # the checker must never take the measurement down
+            cpu = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
 
     import torch
     ctx = Ctx()
@@ -443,6 +513,12 @@ def main():
             resident = hbm_resident(ctx, args, pvar)
         except Exception as ex:       # an extra; must never take the measurement down
             resident = {"error": repr(ex)}
+    sustained = None
+    if args.sustain_seconds > 0 and args.policy == "random":
+        # the closing GPU phase: the primary workload for seconds (the CPU baseline ran first, so the device is busy at
+        # the end of the run, not idle behind a CPU loop)
+        sustained = measure(ctx, args, primary, pvar, args.steps, args.warmup, 1, want_bracketed=False,
+                            fuse=fuse_of[primary], sustain_s=args.sustain_seconds)["sustained"]
 
     if ctx.rank == 0:
         N = args.intruders
@@ -477,7 +553,7 @@ def main():
                                    "one async %s of the [%d, B_local] reward+done slab per chunk, double-buffered "
                                    "(overlaps the next chunk); %d per rank in a timed region"
                                    % (args.exchange, res["chunk"], -(-args.steps // res["chunk"]))},
-            "steady_state": res["steady_state"],
+            "steady_state": res["steady_state"], "sustained": sustained,
             "reps_ms": res["reps_ms"], "timing": "median of %d repetitions of the %d-step region, each bracketed by "
                                                  "barrier + synchronize, max over ranks" % (len(res["reps_ms"]), args.steps),
             "pair_steps_per_sec": res["value"] * N,
@@ -510,14 +586,12 @@ def main():
                                             "registers for the chunk, so a step moves %d B/env instead of %d"
                                             % (fused["chunk"], fused["launch_bytes"] // (fused["chunk"] * res["envs_per_gpu"]),
                                                res["step_bytes"] // res["envs_per_gpu"]))
-        if ctx.world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(args.batch, N, min(16, len(os.sched_getaffinity(0))))
-            except Exception as ex:   # the checker must never take the measurement down
-                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (ex,)}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
         sys.stdout.flush()
+    if args.dump_exchange:
+        exchange_dump(ctx, args, args.dump_exchange)
     if ctx.world > 1:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()

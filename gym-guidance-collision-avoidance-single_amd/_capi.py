@@ -96,7 +96,7 @@ STATE_FIELDS = {
     "mt_has_gauss": (np.int32, "B"), "mt_gauss": (np.float64, "B"),
 }
 
-# every symbol include/uamenv.h declares: (name, restype, argtypes)
+# every symbol include/uamenv.h and include/uamenv_bench.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
     ("uam_config_default", C.c_int, [C.POINTER(UamConfig), C.c_int32, C.c_int32]),
@@ -110,6 +110,7 @@ SYMBOLS = [
     ("uam_rollout", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
     ("uam_rollout_policy", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("uam_steps_per_launch", C.c_int32, [_P, C.c_int32]),
+    ("uam_policy_steps_per_launch", C.c_int32, [_P, C.c_int32]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
     ("uam_nearest", C.c_int, [_P, _P, _P]),

@@ -1695,16 +1695,16 @@ __device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, Own
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
-    else if (p.action_mode == UAM_ACT_CONTINUOUS2) {
-        /* heading += d_heading * a[0], speed += d_speed * a[1]: the un-offset form through the common (a - 1) update —
-         * (float32 + 1.0) - 1.0 is exact in float64 */
-        a0 = (double)af + 1.0; a1 = (double)__uint_as_float(in.w1) + 1.0;
-    }
+    else if (p.action_mode == UAM_ACT_CONTINUOUS2) { a0 = 1.0; a1 = 1.0; }
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
+    /* the command as it multiplies d_heading / d_speed: (a - 1), or the packaged 2Env's un-offset a[0], a[1]
+     * (envs/SingleAircraft2Env.py:281-285; no (a + 1) - 1 detour, which would round away the low bits of |a| < 2^-29) */
+    const bool raw_cmd = p.action_mode == UAM_ACT_CONTINUOUS2;
+    const double dh = raw_cmd ? (double)af : a0 - 1.0, ds = raw_cmd ? (double)__uint_as_float(in.w1) : a1 - 1.0;
     double hd = r.hd, sp = r.sp;
-    hd += c.d_heading * (a0 - 1.0);
+    hd += c.d_heading * dh;
     hd += 0.0 + c.heading_sigma * in.zh;
-    if (has_speed) sp += c.d_speed * (a1 - 1.0);
+    if (has_speed) sp += c.d_speed * ds;
     sp = fmax(c.min_speed, fmin(sp, c.max_speed));
     sp += 0.0 + c.speed_sigma * in.zs;
     double sn, cs;
@@ -1772,11 +1772,13 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
-    else if (p.action_mode == UAM_ACT_CONTINUOUS2) { a0 = (double)af + 1.0; a1 = (double)__uint_as_float(w1) + 1.0; }   /* see own_update */
+    else if (p.action_mode == UAM_ACT_CONTINUOUS2) { a0 = 1.0; a1 = 1.0; }
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
-    hd += c.d_heading * (a0 - 1.0);
+    const bool raw_cmd = p.action_mode == UAM_ACT_CONTINUOUS2;      /* see own_update */
+    const double dh = raw_cmd ? (double)af : a0 - 1.0, ds = raw_cmd ? (double)__uint_as_float(w1) : a1 - 1.0;
+    hd += c.d_heading * dh;
     hd += 0.0 + c.heading_sigma * zh;
-    if (has_speed) sp += c.d_speed * (a1 - 1.0);
+    if (has_speed) sp += c.d_speed * ds;
     sp = fmax(c.min_speed, fmin(sp, c.max_speed));
     sp += 0.0 + c.speed_sigma * zs;
     double sn, cs;

@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "uam_device.h"
+#include "../../include/uamenv_bench.h"
 
 static thread_local char g_err[512] = "";
 static const int NOISE_AHEAD = 16;   /* steps of ownship noise produced per uam_noise_kernel launch */
@@ -1044,6 +1045,13 @@ extern "C" int32_t uam_steps_per_launch(const uam_env* e, int32_t K)
 {
     if (!e || K < 1) return 0;
     return (K > 1 && (many_supported(e) || mt_many_fn(e) || heavy_many_fn(e))) ? K : 1;
+}
+
+/* uam_rollout_policy fuses a chunk only in the ownship-wave flavour of the looped kernel (step_many_impl) */
+extern "C" int32_t uam_policy_steps_per_launch(const uam_env* e, int32_t K)
+{
+    if (!e || K < 1) return 0;
+    return (K > 1 && many_flavour(e) == 1) ? K : 1;
 }
 
 extern "C" int uam_step_many(uam_env* e, int32_t K, const void* action_tape, float* obs_out, float* reward_out,

@@ -344,18 +344,22 @@ class BatchedSingleAircraftEnv:
                                            rew.data_ptr(), done.data_ptr(), info.data_ptr(), self._stream()))
         return self._obs, rew, done, info
 
-    def rollout_into(self, action_tape, rew_out, done_out, info_out=None, obs_out=None):
-        """K steps from a device action tape [K, B(,2)] in ONE C call (uam_rollout) that keeps every step's
-        observation: rewards / dones / info codes go to caller-owned device slabs [K, B]; step k's observation goes
-        to slot k % R of `obs_out` (float32[R, B, D]; default: the env's own [B, D] buffer, R = 1).  The open-loop
-        rollout of baselines/ppo2/runner.py:26-38 with the actions already on the device.  Returns obs_out."""
+    def _check_rollout_buffers(self, K, action_tape, rew_out, done_out, info_out, obs_out, actions_are_output=False):
+        """Every buffer a chunk call hands to the C side, checked here: the library cannot know their sizes, so an
+        undersized, strided, wrongly typed or host tensor would be an out-of-bounds device write.  Returns obs_out
+        (the env's own [1, B, D] view when None).  action_tape may be None only when it is an output."""
         torch = self._torch
         am = self.cfg.action_mode
         dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
-        K = int(action_tape.shape[0])
-        if action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous() \
-                or action_tape.numel() != K * self._act_numel:
-            raise ValueError("action tape must be a contiguous device tensor [K, B(,2)] of %s" % dt)
+        if K < 1:
+            raise ValueError("K must be >= 1")
+        if action_tape is None and not actions_are_output:
+            raise ValueError("an action tape is required")
+        if action_tape is not None and (action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous()
+                                        or action_tape.numel() != K * self._act_numel):
+            raise ValueError("%s must be a contiguous device tensor [K, B(,2)] of %s" % ("actions_out" if actions_are_output else "action tape", dt))
+        if rew_out is None or done_out is None:
+            raise ValueError("rew_out and done_out are required")
         for t, tdt in ((rew_out, torch.float32), (done_out, torch.uint8), (info_out, torch.uint8)):
             if t is not None and (t.dtype != tdt or t.numel() != K * self.num_envs or not t.is_contiguous()
                                   or t.device != self.device):
@@ -363,8 +367,17 @@ class BatchedSingleAircraftEnv:
         if obs_out is None:
             obs_out = self._obs.view(1, self.num_envs, self.obs_dim)
         if obs_out.dtype != torch.float32 or obs_out.dim() != 3 or tuple(obs_out.shape[1:]) != (self.num_envs, self.obs_dim) \
-                or not obs_out.is_contiguous() or obs_out.device != self.device:
+                or not obs_out.is_contiguous() or obs_out.device != self.device or int(obs_out.shape[0]) < 1:
             raise ValueError("obs_out must be a contiguous device tensor float32[R, B, D]")
+        return obs_out
+
+    def rollout_into(self, action_tape, rew_out, done_out, info_out=None, obs_out=None):
+        """K steps from a device action tape [K, B(,2)] in ONE C call (uam_rollout) that keeps every step's
+        observation: rewards / dones / info codes go to caller-owned device slabs [K, B]; step k's observation goes
+        to slot k % R of `obs_out` (float32[R, B, D]; default: the env's own [B, D] buffer, R = 1).  The open-loop
+        rollout of baselines/ppo2/runner.py:26-38 with the actions already on the device.  Returns obs_out."""
+        K = int(action_tape.shape[0])
+        obs_out = self._check_rollout_buffers(K, action_tape, rew_out, done_out, info_out, obs_out)
         capi.check(self._lib.uam_rollout(self._h, K, action_tape.data_ptr(), obs_out.data_ptr(), int(obs_out.shape[0]),
                                          rew_out.data_ptr(), done_out.data_ptr(),
                                          None if info_out is None else info_out.data_ptr(), self._stream()))
@@ -388,36 +401,26 @@ class BatchedSingleAircraftEnv:
         if actions_out is None:
             actions_out = torch.empty((K, B, 2) if am in (capi.ACT_PAIR, capi.ACT_CONTINUOUS2) else (K, B),
                                       dtype=torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32, device=dev)
-        if obs_out is None:
-            obs_out = self._obs.view(1, B, self.obs_dim)
+        obs_out = self._check_rollout_buffers(K, actions_out, rew_out, done_out, info_out, obs_out, actions_are_output=True)
         capi.check(self._lib.uam_rollout_policy(self._h, K, {"random": 0, "goal": 1}[kind], int(seed), obs_out.data_ptr(),
                                                 int(obs_out.shape[0]), rew_out.data_ptr(), done_out.data_ptr(),
                                                 info_out.data_ptr(), actions_out.data_ptr(), self._stream()))
         return obs_out, rew_out, done_out, info_out, actions_out
 
     def steps_per_launch(self, K):
-        """K if a chunk of K steps runs as one launch of the looped kernel on this handle, else 1."""
+        """K if a tape-driven chunk of K steps (step_many / rollout_into) runs as one launch on this handle, else 1."""
         return int(self._lib.uam_steps_per_launch(self._h, int(K)))
+
+    def policy_steps_per_launch(self, K):
+        """The same for rollout_policy: K only where the policy is evaluated inside the looped kernel's launch."""
+        return int(self._lib.uam_policy_steps_per_launch(self._h, int(K)))
 
     def bind_rollout(self, action_tape, rew_out, done_out, info_out=None, obs_out=None):
         """`rollout_into` with the argument checks and pointer extraction done ONCE: returns a zero-argument callable
         that only makes the C call on the stream that is current now.  For hot loops that replay the same buffers
         (a rollout slab ring): the checks cost ~25 us of Python per call, a tenth of a 20-step chunk at 65536 envs."""
-        torch = self._torch
-        if obs_out is None:
-            obs_out = self._obs.view(1, self.num_envs, self.obs_dim)
         K = int(action_tape.shape[0])
-        am = self.cfg.action_mode
-        dt = torch.float32 if am in (capi.ACT_CONTINUOUS1, capi.ACT_CONTINUOUS2) else torch.int32
-        if action_tape.dtype != dt or action_tape.device != self.device or not action_tape.is_contiguous() \
-                or action_tape.numel() != K * self._act_numel:
-            raise ValueError("action tape must be a contiguous device tensor [K, B(,2)] of %s" % dt)
-        for t, tdt in ((rew_out, torch.float32), (done_out, torch.uint8), (info_out, torch.uint8)):
-            if t is not None and (t.dtype != tdt or t.numel() != K * self.num_envs or not t.is_contiguous() or t.device != self.device):
-                raise ValueError("rollout slabs must be contiguous device tensors [K, B]")
-        if obs_out.dtype != torch.float32 or obs_out.dim() != 3 or tuple(obs_out.shape[1:]) != (self.num_envs, self.obs_dim) \
-                or not obs_out.is_contiguous() or obs_out.device != self.device:
-            raise ValueError("obs_out must be a contiguous device tensor float32[R, B, D]")
+        obs_out = self._check_rollout_buffers(K, action_tape, rew_out, done_out, info_out, obs_out)
         fn, h = self._lib.uam_rollout, self._h
         args = (h, K, C.c_void_p(action_tape.data_ptr()), C.c_void_p(obs_out.data_ptr()), int(obs_out.shape[0]),
                 C.c_void_p(rew_out.data_ptr()), C.c_void_p(done_out.data_ptr()),
@@ -686,6 +689,12 @@ class PackagedSingleAircraft2Env(SingleAircraftEnv):
 
     def __init__(self, num_intruders=None, seed=None, device=None, rng="mt19937", precision="exact", config=PackagedConfig,
                  **overrides):
+        n = config.intruder_size if num_intruders is None else num_intruders
+        if int(n) < 1:
+            # the packaged config ships intruder_size = 0 (envs/config.py:8): a map with the ownship and a goal only.
+            # The batched kernels own one quad of intruders per lane and are not built for an empty sweep.
+            raise ValueError("PackagedSingleAircraft2Env: the packaged default intruder_size = 0 is not supported by "
+                             "the HIP path; pass num_intruders >= 1 (INTEGRATION.md, 'Packaged copy')")
         super().__init__(num_intruders, seed, device, rng, precision, config, **overrides)
 
     def _encode_action(self, action):

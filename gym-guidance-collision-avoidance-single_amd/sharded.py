@@ -32,9 +32,13 @@ class RolloutExchange:
     rank's `[K, count]` slabs are contiguous at the front of their halves and the tail is padding.  Works on device tensors over RCCL
     (backend "nccl") and on CPU tensors over gloo (the world_size-2 tests).  This is the object `bench.py` steps
     into, and the parallel step of baselines/common/vec_env/subproc_vec_env.py:63-74 (`step_wait`: one result per
-    worker, stacked) turned inside out: state never moves, only 5 bytes per env-step do."""
+    worker, stacked) turned inside out: state never moves, only 5 bytes per env-step do.
 
-    def __init__(self, dist, K, counts, rank, device, mode="all_gather"):
+    `force=True` issues the collective even in a world of ONE rank (a one-rank process group): the call sequence a rank
+    of the 8-GPU run makes — async gather / all_gather_into_tensor of the uint8 slab, stream-ordered wait — then runs
+    through RCCL on a one-GPU box (tests/test_gpu_rccl.py)."""
+
+    def __init__(self, dist, K, counts, rank, device, mode="all_gather", force=False):
         import torch
         if mode not in ("all_gather", "gather", "none"):
             raise ValueError("mode must be all_gather, gather or none")
@@ -53,7 +57,8 @@ class RolloutExchange:
 
         self._slabs = [make(), make()]
         self._pending = [None, None]
-        receives = self.world > 1 and (mode == "all_gather" or (mode == "gather" and self.rank == 0))
+        self._active = (self.world > 1 or bool(force)) and mode != "none"
+        receives = self._active and (mode == "all_gather" or (mode == "gather" and self.rank == 0))
         self._gathered = [torch.zeros((self.world * KB * 5,), dtype=torch.uint8, device=device) for _ in range(2)] \
             if receives else None
         self.collectives = 0
@@ -73,7 +78,7 @@ class RolloutExchange:
 
     def exchange(self, c):
         """Start the collective of slab c (asynchronous)."""
-        if self.world == 1 or self.mode == "none":
+        if not self._active:
             return
         raw = self._slabs[c & 1][0]
         if self.mode == "all_gather":
@@ -104,7 +109,7 @@ class RolloutExchange:
         last exchanged from slab c, ranks concatenated in global env order (padding columns dropped)."""
         import torch
         k = self.K if k is None else int(k)
-        if self.world == 1 or self.mode == "none":
+        if not self._active:
             rew, done = self.slab(c)
             return rew[:k], done[:k]
         if self._gathered is None:

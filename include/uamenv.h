@@ -243,8 +243,9 @@ int uam_step_many(uam_env* env, int32_t K, const void* action_tape, float* obs_o
 int uam_rollout(uam_env* env, int32_t K, const void* action_tape, float* obs_slots_out, int32_t obs_slots,
                 float* reward_out, uint8_t* done_out, uint8_t* info_out, void* stream);
 
-/* uam_rollout as a CLOSED loop with one of the built-in device-side policies (see uam_policy): before every step the
- * policy of `kind` picks a fresh action from the state the previous step left — the acting loop of
+/* uam_rollout as a CLOSED loop with one of the built-in device-side policies (kind 0: uniform random action from
+ * Philox(policy_seed; env, call number); kind 1: goal seeking — turn toward the goal, full throttle; the same
+ * functions uam_policy of uamenv_bench.h evaluates as a launch of its own): before every step the policy of `kind` picks a fresh action from the state the previous step left — the acting loop of
  * Algorithms/MCTS/Agent.py:25-45 / baselines/ppo2/runner.py:26-38 with a scripted actor.  Small batches run all K
  * steps as ONE launch of the looped kernel, whose ownship wave evaluates the policy on its registers (both built-in
  * policies are functions of the ownship / goal state only); otherwise a policy launch and a step launch are queued
@@ -295,34 +296,9 @@ int uam_her_goal_reward(const uam_config* cfg, int device, const float* achieved
 int uam_her_input_reward(const uam_config* cfg, int device, const float* inputs_dev, int64_t M, int32_t D,
                          float* reward_out_dev, uint8_t* done_out_dev, void* stream);
 
-/* Built-in policies for benchmarks / smoke runs (device, stream-ordered).
- *   kind 0: uniform random action from Philox(seed=policy_seed; env, call#)
- *   kind 1: goal-seeking heuristic (turn toward the goal, accelerate)
- * Writes actions in the handle's action_mode layout to actions_out (device). */
-int uam_policy(uam_env* env, int32_t kind, uint64_t policy_seed, void* actions_out, void* stream);
-
-/* Algorithmic HBM bytes moved by one uam_step over the whole batch (SURVEY §8d
- * accounting restated for the handle's modes); used for the roofline figure. */
-int64_t uam_step_bytes(const uam_env* env);
-
-/* The same for one uam_step_many / uam_rollout call of K steps as this handle would run it: K * uam_step_bytes for
- * queued single-step launches; for the looped kernel, whose env state stays in registers for the whole launch, the
- * state once (24 B per intruder + 88 B per env) plus K times the step's outputs and inputs (observation row, reward,
- * done, info, action, 16 B of noise). */
-int64_t uam_rollout_bytes(const uam_env* env, int32_t K);
-
-/* Average device time in milliseconds per uam_step kernel over the launches
- * recorded between uam_timing_begin and uam_timing_end (hipEvents on `stream`). */
-int uam_timing_begin(uam_env* env, void* stream);
-int uam_timing_end(uam_env* env, void* stream, float* elapsed_ms_out);
-
-/* Per-kernel device times.  While enabled, every uam_step brackets its launch with hipEvents (up to 256
- * steps are sampled; this serialises the launches slightly, so keep it out of throughput runs).
- * uam_kernel_timing_read synchronises `stream` and returns the mean duration in milliseconds of the step
- * kernel over the sampled steps in sweep_ms_out; own_ms_out is always 0 (the ownship phase runs inside the
- * same launch; the argument is kept for ABI stability). */
-int uam_kernel_timing(uam_env* env, int32_t enable);
-int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float* sweep_ms_out, int32_t* samples_out);
+/* Measurement helpers and the built-in action generators used by bench.py, the smoke test and the tools
+ * (uam_policy, uam_step_bytes, uam_rollout_bytes, uam_policy_steps_per_launch, uam_timing_*, uam_kernel_timing*)
+ * are declared in include/uamenv_bench.h: they are not part of the drop-in boundary. */
 
 /* ======================================================================================================
  * Batched MCTS forward model + UCT search (the caller that dominates config 5's

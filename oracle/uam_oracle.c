@@ -462,7 +462,9 @@ static void env_obs(const orc_batch* b, const env_t* e, double* o)
 }
 
 /* Ownship.step, SingleAircraftEnv.py:299-309 (2Env: SingleAircraft2Env.py:294-304) */
-static void own_step(const ctx_t* c, double a0, double a1, int has_speed_cmd)
+/* dh, ds: the heading / speed command as it multiplies d_heading / d_speed: (a - 1) for the Simulators' envs (:302,:305;
+ * 2Env :297), the un-offset a[0], a[1] for the packaged 2Env */
+static void own_step(const ctx_t* c, double dh, double ds, int has_speed_cmd)
 {
     const uam_config* g = &c->b->cfg;
     env_t* e = c->e;
@@ -470,9 +472,9 @@ static void own_step(const ctx_t* c, double a0, double a1, int has_speed_cmd)
     if (g->rng_mode == UAM_RNG_MT19937) {
         zh = mt_gauss(c->b, e->mt);
         /* drawn later in the reference, but nothing else draws in between */
-        e->own_heading += g->d_heading * (a0 - 1.0);
+        e->own_heading += g->d_heading * dh;
         e->own_heading += 0.0 + g->heading_sigma * zh;
-        if (has_speed_cmd) e->own_speed += g->d_speed * (a1 - 1.0);
+        if (has_speed_cmd) e->own_speed += g->d_speed * ds;
         e->own_speed = fmax(g->min_speed, fmin(e->own_speed, g->max_speed));
         zs = mt_gauss(c->b, e->mt);
         e->own_speed += 0.0 + g->speed_sigma * zs;
@@ -485,9 +487,9 @@ static void own_step(const ctx_t* c, double a0, double a1, int has_speed_cmd)
         m_sincos(c->b, 2.0 * M_PI * u2, &sn, &cs);
         zh = r * cs;
         zs = r * sn;
-        e->own_heading += g->d_heading * (a0 - 1.0);
+        e->own_heading += g->d_heading * dh;
         e->own_heading += 0.0 + g->heading_sigma * zh;
-        if (has_speed_cmd) e->own_speed += g->d_speed * (a1 - 1.0);
+        if (has_speed_cmd) e->own_speed += g->d_speed * ds;
         e->own_speed = fmax(g->min_speed, fmin(e->own_speed, g->max_speed));
         e->own_speed += 0.0 + g->speed_sigma * zs;
     }
@@ -628,15 +630,15 @@ static void env_step(const ctx_t* c, int eidx, const void* actions, double* obs,
         a0 = (double)((const int32_t*)actions)[eidx];        /* Discrete3HEREnv.py:408: heading += d_heading * (a - 1) */
         has_speed = 0;
     } else if (g->action_mode == UAM_ACT_CONTINUOUS2) {
-        /* packaged copy, envs/SingleAircraft2Env.py:281-285: heading += d_heading * a[0]; speed += d_speed * a[1].
-         * own_step applies (a - 1): feed it a + 1, exact for the float32-valued actions the boundary carries */
-        a0 = (double)((const float*)actions)[2 * eidx] + 1.0;
-        a1 = (double)((const float*)actions)[2 * eidx + 1] + 1.0;
+        /* packaged copy, envs/SingleAircraft2Env.py:281-285: heading += d_heading * a[0]; speed += d_speed * a[1] —
+         * the command multiplies un-offset (no (a + 1) - 1 detour: that rounds away the low bits of |a| < 2^-29) */
+        own_step(c, (double)((const float*)actions)[2 * eidx], (double)((const float*)actions)[2 * eidx + 1], 1);
+        a0 = a1 = 0.0; has_speed = -1;
     } else {
         a0 = (double)((const float*)actions)[eidx];
         has_speed = 0;
     }
-    own_step(c, a0, a1, has_speed);
+    if (has_speed >= 0) own_step(c, a0 - 1.0, a1 - 1.0, has_speed);
     double r; int d, inf;
     terminal_reward(c, &r, &d, &inf);
     if (g->dynamics == UAM_DYN_RANDINTRUDER) update_headings(c);

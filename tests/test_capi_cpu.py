@@ -18,7 +18,7 @@ def capi():
 
 
 def declared_functions():
-    src = open(os.path.join(ROOT, "include", "uamenv.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("uamenv.h", "uamenv_bench.h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(uam_[a-z_0-9]+)\s*\(", src)))
 

@@ -164,15 +164,22 @@ def _run_bench(extra, timeout=300):
     return json.loads(lines[0])
 
 
-def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
+def test_bench_two_rank_rehearsal_of_its_own_exchange_path(tmp_path):
     """`bench.py --gpus 2` with no rendezvous in the environment: it must start its two ranks itself (gloo, both on
     cuda:0 — the box has one GPU), step each rank's shard in chunks through uam_rollout, exchange one slab per
-    chunk and print ONE line whose strong-scaling field partitions the batch."""
+    chunk and print ONE line whose strong-scaling field partitions the batch.  Its `--dump-exchange` pass then steps
+    ONE partitioned batch from a known tape: what rank 0's collectives gathered from the two HIP-filled slabs must
+    equal, byte for byte, the rewards and dones of one unsharded handle on the same tape."""
+    import numpy as np
+    import torch
+    import uamenv
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    dump = str(tmp_path / "gathered.npz")
     d = _run_bench(["--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "70", "--warmup", "10", "--reps", "2",
-                    "--batch", "8192", "--intruders", "8", "--chunk", "32", "--no-cpu-baseline"])
+                    "--batch", "8192", "--intruders", "8", "--chunk", "32", "--no-cpu-baseline", "--sustain-seconds", "0",
+                    "--dump-exchange", dump])
     assert d["n_gpus"] == 2 and d["steps"] == 70 and d["scaling"] == "weak"
     assert d["config"]["envs_per_gpu"] == 8192 and d["config"]["envs_total"] == 16384
     assert len(d["reps_ms"]) == 2 and d["ms_per_step"] > 0
@@ -181,6 +188,25 @@ def test_bench_two_rank_rehearsal_of_its_own_exchange_path():
     s = d["strong"]
     assert s["scaling"] == "strong" and s["variant"] == "continuous" and s["envs_per_gpu"] == 4096 and s["envs_total"] == 8192
     assert s["value"] > 0 and "cpu_baseline" not in d
+    g = np.load(dump)
+    assert int(g["world"]) == 2 and str(g["mode"]) == "gather" and int(g["collectives"]) == 2
+    tape = g["tape"]
+    K2, Btot = tape.shape
+    assert Btot == 8192 and g["rew"].shape == (K2, Btot) and g["done"].shape == (K2, Btot)
+    one = uamenv.BatchedSingleAircraftEnv(Btot, int(g["intruders"]), variant="continuous", seed=0, auto_reset=True)
+    one.reset()
+    t = torch.from_numpy(tape).to(one.device)
+    rew = torch.empty((K2, Btot), dtype=torch.float32, device=one.device)
+    done = torch.empty((K2, Btot), dtype=torch.uint8, device=one.device)
+    info = torch.empty((K2, Btot), dtype=torch.uint8, device=one.device)
+    half = K2 // 2
+    one.rollout_into(t[:half].contiguous(), rew[:half], done[:half], info[:half])
+    one.rollout_into(t[half:].contiguous(), rew[half:], done[half:], info[half:])
+    torch.cuda.synchronize()
+    assert np.array_equal(g["rew"].view(np.uint32), rew.cpu().numpy().view(np.uint32)), "gathered rewards differ from the unsharded batch"
+    assert np.array_equal(g["done"], done.cpu().numpy()), "gathered dones differ from the unsharded batch"
+    assert float(np.abs(g["rew"]).sum()) > 0
+    one.close()
 
 
 @pytest.mark.parametrize("variant,B,N,K,kind", [

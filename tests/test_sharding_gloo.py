@@ -168,6 +168,42 @@ def test_rollout_exchange_two_ranks_equal_one_batch(tmp_path, G, mode):
         assert not os.path.exists(os.path.join(str(tmp_path), "x1.npz"))
 
 
+def _force_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uamenv.sharded import RolloutExchange
+    K, B = 6, 37
+    ok = True
+    for mode in ("gather", "all_gather"):
+        idle = RolloutExchange(dist, K, [B], 0, torch.device("cpu"), mode=mode)              # a one-rank world: no collective
+        idle.exchange(0)
+        ok = ok and idle.collectives == 0
+        ex = RolloutExchange(dist, K, [B], 0, torch.device("cpu"), mode=mode, force=True)    # ... unless forced
+        g = torch.Generator().manual_seed(3)
+        for c in range(3):
+            ex.begin(c)
+            rew, done = ex.slab(c)
+            rew.copy_(torch.randn((K, B), generator=g))
+            done.copy_(torch.randint(0, 2, (K, B), generator=g).to(torch.uint8))
+            want = (rew.clone(), done.clone())
+            ex.exchange(c)
+            ex.begin(c)
+            r, d = ex.gathered(c)
+            ok = ok and torch.equal(r, want[0]) and torch.equal(d, want[1])
+        ok = ok and ex.collectives == 3 and ex.mode == mode
+    open(os.path.join(out_dir, "force_ok"), "w").write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_in_a_one_rank_world(tmp_path):
+    """RolloutExchange(force=True): the collective is issued even in a world of one rank — what the `-m gpu` test
+    tests/test_gpu_rccl.py relies on to drive the RCCL calls on a one-GPU box."""
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_force_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert open(os.path.join(str(tmp_path), "force_ok")).read() == "1"
+
+
 def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
     """`python bench.py --gpus N` without WORLD_SIZE must start torch.distributed.run as a CHILD and must not have
     imported torch (let alone touched the GPU) in the parent."""
