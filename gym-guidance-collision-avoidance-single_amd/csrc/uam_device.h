@@ -1835,10 +1835,20 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
  * accumulated `vel_dirty_acc` live in registers across the steps of the launch — nothing of the env state is
  * loaded or stored here except by the rare paths (reset: own state + counters through HBM, signalled to the
  * ownship thread through the LDS record); the caller loads before the first step and stores after the last. */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false>
+/* OFFL (looped kernel with a COPY WAVE, sweep_many_body): the sweeping wave neither formats nor stores anything that
+ * leaves the launch.  It parks the step's raw positions (and, when they changed, velocities) and the env's reward /
+ * done / info in LDS; the block's copy wave turns them into the observation rows and the [K, B] output rows while the
+ * sweepers are already in the next step. */
+struct OffBuf {
+    float* px; float* py; float* vx; float* vy;   /* this step's half of the block's [T * 4] slot arrays (LDS) */
+    uint2* out;                                    /* this step's half of the block's [E] (reward bits, done | info << 8) */
+    bool vel_prev;                                 /* some velocity of my quad changed in the previous step */
+};
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false, bool OFFL = false>
 __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k,
                                            Quad<POS64, SH>& q_persist, bool& vel_dirty_acc, int32_t& ncf_persist,
-                                           float4* const rec_persist = nullptr, float* const stage_persist = nullptr
+                                           float4* const rec_persist = nullptr, float* const stage_persist = nullptr,
+                                           OffBuf* const ob = nullptr
 #if UAM_STAMP
                                            , unsigned long long* stamp_acc = nullptr
 #endif
@@ -2156,10 +2166,14 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     UAM_STAMP_AT(5);
     /* ---- per-env outputs (one lane per env) */
     if (env_ok && gl == 0) {
-        const size_t orow = (size_t)k * (size_t)p.B + (size_t)env;
-        p.reward[orow] = reward;
-        p.done[orow] = done ? 1 : 0;
-        if (p.info) p.info[orow] = (uint8_t)info;
+        if constexpr (OFFL) {
+            ob->out[g] = make_uint2(__float_as_uint(reward), (done ? 1u : 0u) | (info << 8));   /* the copy wave stores them */
+        } else {
+            const size_t orow = (size_t)k * (size_t)p.B + (size_t)env;
+            p.reward[orow] = reward;
+            p.done[orow] = done ? 1 : 0;
+            if (p.info) p.info[orow] = (uint8_t)info;
+        }
         if constexpr (PERSIST) {
             /* env.no_conflict of the group's env lives in lane 0's register for the launch (no load -> add -> store
              * round trip inside the step); a reset zeroes it (:94) */
@@ -2180,8 +2194,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     UAM_STAMP_AT(6);
     /* ownship/goal part of the obs: lanes 0 and 1 of the group carry one float4 each */
     const int second = L > 1 ? 1 : 0;
-    float tail[8];
-    {
+    float tail[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (!OFFL) {        /* (the copy wave reads the tail from the env's record itself) */
         const float4 t0 = (gl == 0) ? shp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 t1 = (gl == second || !p.obs_vec || KNN) ? shp[2] : make_float4(0.f, 0.f, 0.f, 0.f);
         tail[0] = t0.x; tail[1] = t0.y; tail[2] = t0.z; tail[3] = t0.w;
@@ -2204,6 +2218,13 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
              * must have reached L2 before the mark is seen */
             if (gl == 0) { __threadfence(); ((uint32_t*)(lds_share + 3 * g))[3] = 0xFFFFFFFFu; }
         }
+        if constexpr (OFFL) {
+            /* the observation of a done env is its reset observation: the copy wave takes the tail from the record */
+            if (gl == 0) {
+                lds_share[3 * g + 1] = make_float4(tail[0], tail[1], tail[2], tail[3]);
+                lds_share[3 * g + 2] = make_float4(tail[4], tail[5], tail[6], tail[7]);
+            }
+        }
         UAM_DRAIN_RARE_LOADS();
     }
 
@@ -2216,6 +2237,18 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         if (vel_dirty) quad_store_vel<POS64, SH>(p, base, q, sp_dirty);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
+    if constexpr (OFFL) {
+        /* raw state of my quad, slot-linear ([thread][4]): two 16-byte LDS stores a step; velocities only when they
+         * changed (respawn / reset) — in that step and in the next one, whose half of the double buffer is the other */
+        static_assert(!POS64 && !SH && (MODE & UAM_MODE_KNN) == 0, "the copy wave formats float32 [x, y, vx, vy] rows");
+        *(float4*)(ob->px + 4 * tid) = make_float4(q.x[0], q.x[1], q.x[2], q.x[3]);
+        *(float4*)(ob->py + 4 * tid) = make_float4(q.y[0], q.y[1], q.y[2], q.y[3]);
+        if (vel_dirty || ob->vel_prev) {
+            *(float4*)(ob->vx + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
+            *(float4*)(ob->vy + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
+        }
+        ob->vel_prev = vel_dirty;
+    } else
     if (obs_k && !(UAM_ABLATE & 2)) {
         float* stage = (PERSIST ? stage_persist : (float*)(lds_raw + (size_t)p.E * 48)) + (size_t)wave_first_g * p.D;
         if constexpr (KNN) {
@@ -2522,7 +2555,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         }
         float4* const rec_k = (OWNW && (k & 1)) ? rec1 : rec0;
 #if UAM_STAMP
-        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, obs_k, q, vel_dirty, ncf, rec_k, stage, stamp_acc);
+        sweep_step<POS64, RNG, MODE, SH, ROS, true, true>(p, lds_raw, k, obs_k, q, vel_dirty, ncf, rec_k, stage, nullptr, stamp_acc);
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
         __syncthreads();                                                       /* A */
         if constexpr (OWNW) __syncthreads();                                   /* B */
@@ -2552,6 +2585,200 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (env < p.B && gl == 0) p.s.no_conflict[env] = ncf;
+}
+
+/* ------------------------------------------------------------------ the looped kernel, three-wave form
+ * (float32 / Philox, plain step, full quads: N = 4 L with L a power of two — BASELINE config 4's per-GPU shards.)
+ * The two-wave form above is issue-bound at one sweeping wave per SIMD (one wave issues at most one vector instruction
+ * every four cycles), and a third of a sweeping wave's step is work that nothing downstream in the step depends on:
+ * formatting the observation rows, copying them out, storing reward / done / info.  Here the block has a third wave,
+ * the COPY WAVE, that does all of it one step behind:
+ *   sweeping waves   step k on registers; park raw positions (velocities when they changed) and the env's
+ *                    (reward, done | info << 8) in LDS — two 16-byte LDS stores and one 8-byte one per lane and step
+ *   ownship wave     one step AHEAD, as in the two-wave form (three record sets now: the copy wave still reads step
+ *                    k's observation tail while step k + 2's record is being written)
+ *   copy wave        one step BEHIND: after barrier B of step k it formats step k's rows from the parked state
+ *                    (the same float32 operations as quad_obs, 16 B per lane, non-temporal) and stores the outputs
+ * The lane-group width is a template parameter here (LC), with everything derived from it — group index, reduction
+ * depth, row width, the copy wave's divisions — constant-folded: the kernel takes a by-value copy of the parameters
+ * with those fields overwritten by constants.  The host picks this form only when the handle's geometry matches. */
+template <int MODE, bool ROS, int LC, int OBSC>
+__device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned char* lds_raw)
+{
+    static_assert(LC >= 1 && LC <= 64 && (LC & (LC - 1)) == 0, "lane-group width: a power of two");
+    static_assert(OBSC == UAM_OBS_NORM4 || OBSC == UAM_OBS_RAW4, "four floats per intruder");
+    constexpr int LS = LC == 1 ? 0 : LC == 2 ? 1 : LC == 4 ? 2 : LC == 8 ? 3 : LC == 16 ? 4 : LC == 32 ? 5 : 6;
+    constexpr int NC = 4 * LC, DC = 4 * NC + 8, CR = NC + 2;      /* intruders, row width, float4 chunks per row */
+    UamParams p = p_in;
+    p.L = LC; p.lshift = LS; p.Q = LC; p.N = NC; p.Np = NC; p.D = DC; p.obs_w = 4; p.obs_vec = 1; p.obs_mode = OBSC;
+    p.knn = 0; p.track_ep = 0; p.shaped = 0; p.obs_direct = 0;
+    const int K = p.many_K;
+    const int T = (int)blockDim.x - 128;              /* sweeping threads; then the ownship wave, then the copy wave */
+    const int E = T >> LS;
+    p.E = E;
+    const int tid = threadIdx.x;
+    float4* const rec = (float4*)lds_raw;             /* three sets of [E][3] float4 records */
+    uint2* const outb = (uint2*)(lds_raw + (size_t)E * 144);          /* two halves of [E] */
+    float* const slots = (float*)(lds_raw + (size_t)E * 160);         /* px, py, vx, vy: two halves of [T * 4] each */
+    const int SH4 = T * 4;
+    float* const spx = slots; float* const spy = slots + 2 * SH4; float* const svx = slots + 4 * SH4; float* const svy = slots + 6 * SH4;
+    const size_t slot_elems = (size_t)p.B * (size_t)DC;
+
+    if (tid >= T + 64) {
+        /* ---------------- copy wave */
+        const int lane = tid - T - 64;
+        const int env0 = blockIdx.x * E;
+        const int rows = min(E, p.B - env0);
+        int slot = 0, r3 = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            float* obs_k = nullptr;
+            if (p.obs) {
+                if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
+                else if (k == K - 1) obs_k = p.obs;
+            }
+            __syncthreads();                                                   /* A: sweep k done */
+            __syncthreads();                                                   /* B */
+            const int half = k & 1;
+            const float4* const rec_k = rec + 3 * E * r3;
+            r3 = r3 == 2 ? 0 : r3 + 1;
+            if (lane < rows) {
+                const uint2 o = outb[half * E + lane];
+                const size_t orow = (size_t)k * (size_t)p.B + (size_t)(env0 + lane);
+                p.reward[orow] = __uint_as_float(o.x);
+                p.done[orow] = (uint8_t)(o.y & 0xFFu);
+                if (p.info) p.info[orow] = (uint8_t)(o.y >> 8);
+            }
+            if (obs_k) {
+                typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
+                uam_f32x4* const dst = (uam_f32x4*)(obs_k + (size_t)env0 * DC);
+                const float* const hx = spx + half * SH4; const float* const hy = spy + half * SH4;
+                const float* const hvx = svx + half * SH4; const float* const hvy = svy + half * SH4;
+                const int chunks = rows * CR;
+#pragma unroll 2
+                for (int c = lane; c < chunks; c += 64) {
+                    const int row = c / CR, col = c - row * CR;
+                    uam_f32x4 v;
+                    if (col < NC) {
+                        const int i = row * NC + col;
+                        const float x = hx[i], y = hy[i], vx = hvx[i], vy = hvy[i];
+                        if constexpr (OBSC == UAM_OBS_NORM4) {      /* quad_obs, operation for operation */
+                            v.x = x * p.inv_W32; v.y = y * p.inv_H32;
+                            v.z = (vx + p.vmax32) * p.inv_vden32; v.w = (vy + p.vmax32) * p.inv_vden32;
+                        } else { v.x = x; v.y = y; v.z = vx; v.w = vy; }
+                    } else {
+                        const float4 t = rec_k[3 * row + 1 + (col - NC)];
+                        v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+                    }
+                    __builtin_nontemporal_store(v, &dst[c]);
+                }
+            }
+        }
+        return;
+    }
+
+    if (tid >= T) {
+        /* ---------------- ownship wave (see sweep_many_body; record sets rotate over three) */
+        const UamParams& pk = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int lane = tid - T;
+        const int e = blockIdx.x * E + lane;
+        const bool owns = lane < E && e < p.B;
+        OwnRegs own;
+        OwnIn cur, nxt;
+        if (owns) {
+            own_load(p, e, own);
+            own_inputs<UAM_RNG_PHILOX>(pk, e, 0, own, cur);
+            own_update<true>(pk, *pk.c, own, cur, rec + 3 * lane);           /* step 0 */
+            if (K > 1) own_inputs<UAM_RNG_PHILOX>(pk, e, 1, own, cur);
+        }
+        __syncthreads();
+        int r3 = 0;
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            float4* const rec_k = rec + 3 * E * r3;
+            r3 = r3 == 2 ? 0 : r3 + 1;
+            float4* const rec_n = rec + 3 * E * r3;
+            if (owns && k + 1 < K) {
+                own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
+                if (k + 2 < K) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt);
+            }
+            __syncthreads();                                                   /* A: sweep k done */
+            if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
+                own_reload(p, e, own);                                         /* env was reset in step k */
+                if (k + 1 < K) {
+                    if (p.many_policy >= 0) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 1, own, cur);   /* the policy sees the new episode */
+                    own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
+                    if (k + 2 < K && p.many_policy >= 0) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt);
+                }
+            }
+            cur = nxt;
+            __syncthreads();                                                   /* B: record k+1 final */
+        }
+        if (owns) own_store(p, e, own);
+        return;
+    }
+
+    /* ---------------- sweeping waves */
+    const int g = tid >> LS, gl = tid & (LC - 1);
+    const int env = blockIdx.x * E + g;
+    const bool quad_ok = env < p.B;
+    const size_t base = (size_t)env * NC + 4u * gl;
+    Quad<false, false> q;
+    bool vel_dirty = false;
+#if UAM_STAMP
+    unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    quad_load<false, false>(p, base, quad_ok, q);
+    int32_t ncf = (env < p.B && gl == 0) ? p.s.no_conflict[env] : 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0): see sweep_many_body */
+    /* both halves of the velocity slots start out current */
+    *(float4*)(svx + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
+    *(float4*)(svy + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
+    *(float4*)(svx + SH4 + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
+    *(float4*)(svy + SH4 + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
+    OffBuf ob;
+    ob.vel_prev = false;
+    __syncthreads();
+    int r3 = 0;
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        float4* const rec_k = rec + 3 * E * r3;
+        r3 = r3 == 2 ? 0 : r3 + 1;
+        const int half = k & 1;
+        ob.px = spx + half * SH4; ob.py = spy + half * SH4; ob.vx = svx + half * SH4; ob.vy = svy + half * SH4;
+        ob.out = outb + half * E;
+#if UAM_STAMP
+        sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob, stamp_acc);
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        __syncthreads();                                                       /* A */
+        __syncthreads();                                                       /* B */
+        stamp_acc[9] += __builtin_amdgcn_s_memtime() - tb;
+#else
+        sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob);
+        __syncthreads();                                                       /* A */
+        __syncthreads();                                                       /* B */
+#endif
+    }
+#if UAM_STAMP
+    if (p.actions_out && (tid & 63) == 0) {
+        unsigned long long* dst = (unsigned long long*)p.actions_out + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * UAM_NSTAMP;
+        for (int i = 0; i < UAM_NSTAMP; i++) dst[i] = stamp_acc[i];
+    }
+#endif
+    if (quad_ok) {
+        quad_store_pos<false, false>(p, base, q);
+        if (vel_dirty) quad_store_vel<false, false>(p, base, q);
+        p.s.qf[base >> 2] = (uint8_t)q.flags;
+    }
+    if (env < p.B && gl == 0) p.s.no_conflict[env] = ncf;
+}
+
+template <int MODE, bool ROS, int LC, int OBSC>
+__global__ void UAM_MANY_BOUNDS uam_sweep_many3_kernel(const UamParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    sweep_many3_body<MODE, ROS, LC, OBSC>(p, lds_raw);
 }
 
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>

@@ -46,6 +46,7 @@ struct uam_env {
     int num_cus;                /* compute units of the device (hipDeviceProp_t::multiProcessorCount) */
     int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
+    int many3_resident_blocks;  /* the same for the three-wave form (0: the handle's geometry has no such instance) */
     bool shared_stream;         /* UAM_RNG_MT19937_SHARED: cfg.rng_mode is normalised to UAM_RNG_MT19937, every env uses stream 0 */
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
@@ -85,6 +86,8 @@ static inline size_t lds_step(const uam_env* e, bool staged);
 static bool many_instance_exists(const uam_env* e);
 static UamSweepFn many4_fn(const uam_env* e);
 static inline size_t lds_many(const uam_env* e, int fl, bool staged);
+static UamSweepFn many3_fn(const uam_env* e);
+static inline size_t lds_many3(const uam_env* e);
 
 extern "C" const char* uam_last_error(void) { return g_err; }
 extern "C" const char* uam_version(void) { return "uamenv-hip 0.2 (gfx950, abi 2)"; }
@@ -458,6 +461,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     }
     e->many_resident_blocks = 0;
     e->many4_resident_blocks = 0;
+    e->many3_resident_blocks = 0;
     e->many_obs_direct = 0;
     if (!rc && many_instance_exists(e)) {
         int per_cu = 0;
@@ -467,6 +471,11 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
             per_cu = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many4_fn(e), e->T, lds_many(e, 2, true)) != hipSuccess) per_cu = 0;
             e->many4_resident_blocks = per_cu * e->num_cus;
+        }
+        if (many3_fn(e)) {
+            per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e), e->Tm + 128, lds_many3(e)) != hipSuccess) per_cu = 0;
+            e->many3_resident_blocks = per_cu * e->num_cus;
         }
         if (const char* od = getenv("UAMENV_OBS_DIRECT")) e->many_obs_direct = atoi(od);   /* development override */
     }
@@ -650,6 +659,32 @@ static UamSweepFn many4_fn(const uam_env* e)
     return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, false>;
 }
 
+/* the three-wave form (uam_sweep_many3_kernel: sweeping waves + ownship wave + copy wave, compile-time lane-group width):
+ * plain step, full quads (N = 4 L, L a power of two), four floats per intruder in the observation */
+template <int LC>
+static UamSweepFn many3_fn_l(const uam_env* e)
+{
+    if (e->cfg.obs_mode == UAM_OBS_RAW4) return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_RAW4>;
+    return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_NORM4>;
+}
+static UamSweepFn many3_fn(const uam_env* e)
+{
+    if (!many_instance_exists(e) || e->cfg.dynamics == UAM_DYN_RANDINTRUDER || e->cfg.shaped_reward || e->hold_sh ||
+        e->cfg.random_own_start || e->cfg.track_episodes)
+        return nullptr;
+    if (e->cfg.obs_mode != UAM_OBS_NORM4 && e->cfg.obs_mode != UAM_OBS_RAW4) return nullptr;
+    if (e->cfg.num_intruders != 4 * e->L) return nullptr;          /* full quads, and Q = L */
+    switch (e->L) {
+    case 2: return many3_fn_l<2>(e);
+    case 4: return many3_fn_l<4>(e);
+    case 8: return many3_fn_l<8>(e);
+    case 16: return many3_fn_l<16>(e);
+    default: return nullptr;
+    }
+}
+/* LDS of one block: three record sets, two halves of the per-env outputs, two halves of the px / py / vx / vy slots */
+static inline size_t lds_many3(const uam_env* e) { return (size_t)e->Em * 160 + (size_t)e->Tm * 128; }
+
 /* launch geometry of the looped kernel by flavour (1: ownship wave, 2: none) */
 static inline int many_E(const uam_env* e, int fl) { return fl == 2 ? e->E : e->Em; }
 static inline int many_threads(const uam_env* e, int fl) { return fl == 2 ? e->T : e->Tm + 64; }
@@ -682,13 +717,24 @@ static int many_flavour(const uam_env* e)
     return 0;
 }
 
+/* the ownship-wave flavour runs in its three-wave form where the handle has one, the grid is resident in one round with the
+ * extra wave per block, and the observation (if any) takes the 16-byte path */
+static bool use_many3(const uam_env* e, const UamParams& p, int fl)
+{
+    if (fl != 1 || !many3_fn(e) || grid_many(e, 1) > e->many3_resident_blocks) return false;
+    if (p.obs && !p.obs_vec) return false;
+    if (const char* f = getenv("UAMENV_MANY3")) { if (!strcmp(f, "off")) return false; }   /* development override */
+    return true;
+}
+
 static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
 {
     const int fl = many_flavour(e);
     p.E = many_E(e, fl);
     p.obs_direct = e->many_obs_direct;
-    dim3 grid(grid_many(e, fl)), block(many_threads(e, fl));
-    const size_t lds = lds_many(e, fl, p.obs_vec != 0);
+    const bool m3 = use_many3(e, p, fl);
+    dim3 grid(grid_many(e, fl)), block(many_threads(e, fl) + (m3 ? 64 : 0));
+    const size_t lds = m3 ? lds_many3(e) : lds_many(e, fl, p.obs_vec != 0);
 #if UAM_STAMP
     if (fl == 1) {   /* development build: per-phase s_memtime sums of every sweeping wave, averaged and printed per launch */
         const int nw = grid_many(e, 1) * (e->Tm / 64);
@@ -696,7 +742,7 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
         if (dcap < nw) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void**)&dbuf, (size_t)nw * UAM_NSTAMP * 8); dcap = nw; }
         (void)hipMemsetAsync(dbuf, 0, (size_t)nw * UAM_NSTAMP * 8, st);
         p.actions_out = dbuf;
-        hipLaunchKernelGGL(many_fn(e), grid, block, lds, st, p);
+        hipLaunchKernelGGL(m3 ? many3_fn(e) : many_fn(e), grid, block, lds, st, p);
         std::vector<unsigned long long> h((size_t)nw * UAM_NSTAMP);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
@@ -709,7 +755,7 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
         return;
     }
 #endif
-    hipLaunchKernelGGL(fl == 2 ? many4_fn(e) : many_fn(e), grid, block, lds, st, p);
+    hipLaunchKernelGGL(fl == 2 ? many4_fn(e) : (m3 ? many3_fn(e) : many_fn(e)), grid, block, lds, st, p);
 }
 
 static bool many_supported(const uam_env* e) { return many_flavour(e) != 0; }
