@@ -47,6 +47,9 @@
 #ifndef UAM_STAMP
 #define UAM_STAMP 0
 #endif
+#ifndef UAM_SWEEP_PRIO
+#define UAM_SWEEP_PRIO 3      /* s_setprio of the sweeping waves of the three-wave looped kernel */
+#endif
 #if UAM_STAMP
 #define UAM_NSTAMP 16
 #define UAM_STAMP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -1669,13 +1672,16 @@ __device__ __attribute__((noinline)) uint2 uam_policy_eval_fn(const UamParams* p
 /* looped kernel: the inputs of step k for env e — noise from the buffer drawn ahead; the action from the tape, or from
  * the built-in policy evaluated on the ownship registers as they are NOW (i.e. after the update of step k - 1).  The
  * action taken is recorded in actions_out when the caller asked for it. */
+/* pfn: the parameters as the out-of-line policy function gets them (a pointer: pass the kernarg segment when `p` is a
+ * by-value copy in registers, whose address would force it into scratch) */
 template <int RNG, bool POLICY = true>
-__device__ __forceinline__ void own_inputs(const UamParams& p, const int e, const int k, const OwnRegs& r, OwnIn& in)
+__device__ __forceinline__ void own_inputs(const UamParams& p, const int e, const int k, const OwnRegs& r, OwnIn& in,
+                                           const UamParams* const pfn)
 {
     if (!POLICY || p.many_policy < 0) { own_fetch_inputs<RNG>(p, e, k, in); return; }
     const double2 z = p.noise[(size_t)k * (size_t)p.B + e];
     in.zh = z.x; in.zs = z.y;
-    const uint2 a = uam_policy_eval_fn(&p, p.many_policy, e, r.ox, r.oy, r.hd, r.gx, r.gy, p.policy_call + (uint32_t)k);
+    const uint2 a = uam_policy_eval_fn(pfn, p.many_policy, e, r.ox, r.oy, r.hd, r.gx, r.gy, p.policy_call + (uint32_t)k);
     in.w0 = a.x; in.w1 = a.y;
     if (p.actions_out) {
         if (p.action_mode == UAM_ACT_PAIR || p.action_mode == UAM_ACT_CONTINUOUS2) ((uint2*)p.actions_out)[(size_t)k * (size_t)p.B + e] = make_uint2(in.w0, in.w1);
@@ -1684,35 +1690,48 @@ __device__ __forceinline__ void own_inputs(const UamParams& p, const int e, cons
 }
 
 /* the update itself: registers in, registers + the env's 48-byte LDS record out */
-template <bool KC>
-__device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, OwnRegs& r, const OwnIn& in, float4* sh,
-                                           const bool writes = true)
+/* the fields of the cold configuration own_update reads, by value */
+struct OwnCold {
+    double d_heading, heading_sigma, d_speed, min_speed, max_speed, speed_sigma, goal_r, wall_pen, goal_rew, step_pen,
+        dense_div, inv_2vmax, inv_vrange, inv_W, inv_H;
+    __device__ __forceinline__ void load(UamColdPtr c)
+    {
+        d_heading = c->d_heading; heading_sigma = c->heading_sigma; d_speed = c->d_speed; min_speed = c->min_speed;
+        max_speed = c->max_speed; speed_sigma = c->speed_sigma; goal_r = c->goal_r; wall_pen = c->wall_pen;
+        goal_rew = c->goal_rew; step_pen = c->step_pen; dense_div = c->dense_div; inv_2vmax = c->inv_2vmax;
+        inv_vrange = c->inv_vrange; inv_W = c->inv_W; inv_H = c->inv_H;
+    }
+};
+
+/* CT: the cold configuration where it lies — the constant-address-space struct behind UamParams::c (scalar loads at
+ * the point of use: the sweeping kernels, which must not hold ~40 SGPRs for it), or a by-value copy (the ownship wave of
+ * the three-wave looped kernel: loaded once, nothing of it fetched inside the K loop) */
+/* action words -> the command as it multiplies d_heading / d_speed: (a - 1) for the Simulators' envs (:302,:305; 2Env
+ * :297), or the packaged 2Env's un-offset a[0], a[1] (envs/SingleAircraft2Env.py:281-285; no (a + 1) - 1 detour, which
+ * would round away the low bits of |a| < 2^-29) */
+__device__ __forceinline__ void own_decode(const UamParams& p, const OwnIn& in, double& dh, double& ds, bool& has_speed)
 {
     const int ai0 = (int)in.w0, ai1 = (int)in.w1;
     const float af = __uint_as_float(in.w0);
     double a0, a1;
-    bool has_speed = true;
+    has_speed = true;
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
     else if (p.action_mode == UAM_ACT_PAIR) { a0 = (double)ai0; a1 = (double)ai1; }
     else if (p.action_mode == UAM_ACT_DISCRETE3) { a0 = (double)ai0; a1 = 1.0; has_speed = false; }   /* Discrete3HEREnv.py:408 */
     else if (p.action_mode == UAM_ACT_CONTINUOUS2) { a0 = 1.0; a1 = 1.0; }
     else { a0 = (double)af; a1 = 1.0; has_speed = false; }
-    /* the command as it multiplies d_heading / d_speed: (a - 1), or the packaged 2Env's un-offset a[0], a[1]
-     * (envs/SingleAircraft2Env.py:281-285; no (a + 1) - 1 detour, which would round away the low bits of |a| < 2^-29) */
     const bool raw_cmd = p.action_mode == UAM_ACT_CONTINUOUS2;
-    const double dh = raw_cmd ? (double)af : a0 - 1.0, ds = raw_cmd ? (double)__uint_as_float(in.w1) : a1 - 1.0;
-    double hd = r.hd, sp = r.sp;
-    hd += c.d_heading * dh;
-    hd += 0.0 + c.heading_sigma * in.zh;
-    if (has_speed) sp += c.d_speed * ds;
-    sp = fmax(c.min_speed, fmin(sp, c.max_speed));
-    sp += 0.0 + c.speed_sigma * in.zs;
-    double sn, cs;
-    sincos_sel<KC>(hd, &sn, &cs);
-    const double vx = sp * cs, vy = sp * sn;
-    const float ox = (float)((double)r.ox + vx);      /* float32 position += float64 velocity */
-    const float oy = (float)((double)r.oy + vy);
-    const double gx = r.gx, gy = r.gy;
+    dh = raw_cmd ? (double)af : a0 - 1.0;
+    ds = raw_cmd ? (double)__uint_as_float(in.w1) : a1 - 1.0;
+}
+
+/* the env-level tail of the step from the updated ownship: goal distance, reward tail, tail code, observation tail ->
+ * the env's 48-byte record */
+template <typename CT>
+__device__ __forceinline__ void own_finish(const UamParams& p, const CT& c, const float ox, const float oy, const double vx,
+                                           const double vy, const double sp, const double hd, const double gx, const double gy,
+                                           float4* sh, const bool writes)
+{
     /* dist(drone, goal): float32 - float64 -> float64 with the BLAS ddot FMA form */
     const double dx = (double)ox - gx, dy = (double)oy - gy;
     const double dg = __builtin_sqrt(uam_fma(dy, dy, dx * dx));
@@ -1735,12 +1754,153 @@ __device__ __forceinline__ void own_update(const UamParams& p, UamColdRef c, Own
         t[0] = ox; t[1] = oy; t[2] = (float)vx; t[3] = (float)vy;
         t[4] = (float)sp; t[5] = (float)hd; t[6] = (float)gx; t[7] = (float)gy;
     }
-    r.ox = ox; r.oy = oy; r.hd = hd; r.sp = sp; r.vx = vx; r.vy = vy;
     if (writes) {
         sh[0] = make_float4(ox, oy, rew, __uint_as_float(wall ? 2u : (hit ? 1u : 0u)));   /* tail code: 0 none, 1 goal, 2 wall */
         sh[1] = make_float4(t[0], t[1], t[2], t[3]);
         sh[2] = make_float4(t[4], t[5], t[6], t[7]);
     }
+}
+
+template <bool KC, typename CT>
+__device__ __forceinline__ void own_update(const UamParams& p, const CT& c, OwnRegs& r, const OwnIn& in, float4* sh,
+                                           const bool writes = true)
+{
+    double dh, ds;
+    bool has_speed;
+    own_decode(p, in, dh, ds, has_speed);
+    double hd = r.hd, sp = r.sp;
+    hd += c.d_heading * dh;
+    hd += 0.0 + c.heading_sigma * in.zh;
+    if (has_speed) sp += c.d_speed * ds;
+    sp = fmax(c.min_speed, fmin(sp, c.max_speed));
+    sp += 0.0 + c.speed_sigma * in.zs;
+    double sn, cs;
+    sincos_sel<KC>(hd, &sn, &cs);
+    const double vx = sp * cs, vy = sp * sn;
+    const float ox = (float)((double)r.ox + vx);      /* float32 position += float64 velocity */
+    const float oy = (float)((double)r.oy + vy);
+    own_finish(p, c, ox, oy, vx, vy, sp, hd, r.gx, r.gy, sh, writes);
+    r.ox = ox; r.oy = oy; r.hd = hd; r.sp = sp; r.vx = vx; r.vy = vy;
+}
+
+/* ------------------------------------------------------------------ the ownship wave, J steps per pass
+ * An env's ownship update is a serial chain per step (fp64 trig, square root, division: ~3000 cycles for one wave), but
+ * across the steps of an ACTION TAPE only three short recurrences are serial — heading (two additions a step), speed
+ * (clamp and two additions), position (one float32-rounded addition per axis) — because the actions and the noise of
+ * every step are known in advance and nothing else of the env feeds back into the ownship.  So the ownship wave of the
+ * three-wave looped kernel gives each env J = 64 / E lanes, lane j taking step kb + j of a batch of J steps:
+ *   inputs of the J steps loaded in parallel; the heading recurrence walked through the J lanes (DPP row_shr:1);
+ *   sincos of all J headings in parallel; the speed recurrence walked; velocities in parallel; the position recurrence
+ *   walked; goal distance, reward tail and observation tail of all J steps in parallel; J records written.
+ * Every operation is the one own_update performs, on the same values in the same order: bit-identical.  One pass per J
+ * steps instead of one update per step: the ownship wave drops from ~3200 to ~500 cycles a step and off the critical path.
+ * A reset invalidates the env's records after the step that ended the episode; the wave recomputes them (j_first = the
+ * first step to redo) from the new episode's state for the lanes selected by `sel`.
+ * st: in = the state before step kb + j_first, out = the state after the last step computed (both replicated on the
+ * env's J lanes).  rec_ring: [ring][E][3] float4; slot_kb = ring slot of step kb. */
+#define UAM_DPP_ROW_SHR1 0x111
+/* the inputs of lane j's step of the batch starting at kb (issued a batch ahead: the pass itself then waits for nothing) */
+__device__ __forceinline__ void own_batch_fetch(const UamParams& p, const int e, const bool sel, const int j, const int J,
+                                                const int kb, const int j_first, const int K, OwnIn& in)
+{
+    in.w0 = 0; in.w1 = 0; in.zh = 0.0; in.zs = 0.0;
+    if (sel && j >= j_first && kb + j < K) own_fetch_inputs<UAM_RNG_PHILOX>(p, e, kb + j, in);
+}
+
+/* The pass in pieces, so that the ownship wave can spread it over three steps' windows (it has to arrive at every step's
+ * barrier, and a whole pass — ~11 k cycles of mostly dependent fp64 operations — is far longer than a sweep step):
+ * window 1: P1a = decode, heading and speed recurrences, P1b = sincos, velocity; window 2: P2a = position recurrence,
+ * P2b = goal distance / reward / observation tail, records; window 3: P3 = the end state to the env's lanes.
+ * (One piece per window over five windows was tried: the dispatch cost the wave more than the smoother load gained —
+ * 8192 x 32: 1.80 against 1.71 us per step.) */
+struct OwnBatch { double hd, sp, vx, vy; float ox, oy; };
+
+__device__ __forceinline__ void own_batch_p1a(const UamParams& p, const OwnCold& c, const OwnIn& in, const int j, const int j_first,
+                                              const int j_last, const OwnRegs& st, OwnBatch& w)
+{
+    double dh, ds;
+    bool has_speed;
+    own_decode(p, in, dh, ds, has_speed);
+    /* the two recurrences that do not need the trig, walked through the env's lanes together (lane s takes lane
+     * s - 1's results):  hd += d_heading * dh; hd += 0.0 + heading_sigma * zh;
+     *                    sp += d_speed * ds (if commanded); sp = clamp(sp); sp += 0.0 + speed_sigma * zs */
+    const double hinc = c.d_heading * dh, hnoise = 0.0 + c.heading_sigma * in.zh;
+    const double sinc = c.d_speed * ds, snoise = 0.0 + c.speed_sigma * in.zs;
+    double hd = st.hd, sp = st.sp;
+#pragma unroll 1
+    for (int s = j_first; s <= j_last; s++) {
+        const double ph = dpp_mov<UAM_DPP_ROW_SHR1>(hd), ps = dpp_mov<UAM_DPP_ROW_SHR1>(sp);
+        if (j == s) {
+            double h = s == j_first ? st.hd : ph;
+            h += hinc;
+            h += hnoise;
+            hd = h;
+            double v = s == j_first ? st.sp : ps;
+            if (has_speed) v += sinc;
+            v = fmax(c.min_speed, fmin(v, c.max_speed));
+            v += snoise;
+            sp = v;
+        }
+    }
+    w.hd = hd; w.sp = sp;
+}
+
+template <bool KC>
+__device__ __forceinline__ void own_batch_p1b(OwnBatch& w)
+{
+    double sn, cs;
+    sincos_sel<KC>(w.hd, &sn, &cs);
+    w.vx = w.sp * cs; w.vy = w.sp * sn;
+}
+
+__device__ __forceinline__ void own_batch_p2a(const int j, const int j_first, const int j_last, const OwnRegs& st, OwnBatch& w)
+{
+    float ox = st.ox, oy = st.oy;
+#pragma unroll 1
+    for (int s = j_first; s <= j_last; s++) {
+        const float px = dpp_mov<UAM_DPP_ROW_SHR1>(ox), py = dpp_mov<UAM_DPP_ROW_SHR1>(oy);
+        if (j == s) {
+            ox = (float)((double)(s == j_first ? st.ox : px) + w.vx);      /* float32 position += float64 velocity */
+            oy = (float)((double)(s == j_first ? st.oy : py) + w.vy);
+        }
+    }
+    w.ox = ox; w.oy = oy;
+}
+
+__device__ __forceinline__ void own_batch_p2b(const UamParams& p, const OwnCold& c, const bool act, const int le, const int j,
+                                              const OwnRegs& st, const OwnBatch& w, float4* const rec_ring, const int E,
+                                              const int ring, const int slot_kb)
+{
+    int slot = slot_kb + j;
+    if (slot >= ring) slot -= ring;
+    own_finish(p, c, w.ox, w.oy, w.vx, w.vy, w.sp, w.hd, st.gx, st.gy, rec_ring + 3 * E * slot + 3 * le, act);
+}
+
+__device__ __forceinline__ void own_batch_p3(const bool sel, const int j, const int j_first, const int j_last, OwnRegs& st,
+                                             const OwnBatch& w)
+{
+    if (j_first <= j_last) {
+        /* the state after the last step computed, to every lane of the env */
+        const int src = ((int)(threadIdx.x & 63) - j) + j_last;
+        const float nox = __shfl(w.ox, src), noy = __shfl(w.oy, src);
+        const double nhd = __shfl(w.hd, src), nsp = __shfl(w.sp, src), nvx = __shfl(w.vx, src), nvy = __shfl(w.vy, src);
+        if (sel) { st.ox = nox; st.oy = noy; st.hd = nhd; st.sp = nsp; st.vx = nvx; st.vy = nvy; }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void own_batch_pass(const UamParams& p, const OwnCold& c, const OwnIn& in, const bool sel, const int le,
+                                               const int j, const int J, const int kb, const int j_first, const int K,
+                                               OwnRegs& st, float4* const rec_ring, const int E, const int ring, const int slot_kb)
+{
+    const int j_last = min(J, K - kb) - 1;
+    const bool act = sel && j >= j_first && j <= j_last;
+    OwnBatch w;
+    own_batch_p1a(p, c, in, j, j_first, j_last, st, w);
+    own_batch_p1b<KC>(w);
+    own_batch_p2a(j, j_first, j_last, st, w);
+    own_batch_p2b(p, c, act, le, j, st, w, rec_ring, E, ring, slot_kb);
+    own_batch_p3(sel, j, j_first, j_last, st, w);
 }
 
 /* single-step form (uam_sweep_kernel): load, update, store in one function — the same arithmetic as own_update,
@@ -1843,6 +2003,7 @@ struct OffBuf {
     float* px; float* py; float* vx; float* vy;   /* this step's half of the block's [T * 4] slot arrays (LDS) */
     uint2* out;                                    /* this step's half of the block's [E] (reward bits, done | info << 8) */
     bool vel_prev;                                 /* some velocity of my quad changed in the previous step */
+    bool had_reset;                                /* out: my env was reset in this step (its later ownship records are being redone) */
 };
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false, bool OFFL = false>
 __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k,
@@ -1875,7 +2036,8 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     const int env = blockIdx.x * p.E + g;
     const int wave_first_g = (tid & ~63) >> p.lshift;
     const int env_first = blockIdx.x * p.E + wave_first_g;
-    const bool env_ok = env < p.B;
+    /* (three-wave looped kernel: a block may hold fewer envs than its sweeping lanes could take) */
+    const bool env_ok = env < p.B && (!OFFL || g < p.E);
     const bool quad_ok = env_ok && gl < p.Q;
     const size_t base = (size_t)env * p.Np + 4u * gl;
 
@@ -2219,6 +2381,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             if (gl == 0) { __threadfence(); ((uint32_t*)(lds_share + 3 * g))[3] = 0xFFFFFFFFu; }
         }
         if constexpr (OFFL) {
+            ob->had_reset = true;
             /* the observation of a done env is its reset observation: the copy wave takes the tail from the record */
             if (gl == 0) {
                 lds_share[3 * g + 1] = make_float4(tail[0], tail[1], tail[2], tail[3]);
@@ -2482,9 +2645,9 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         OwnIn cur, nxt;
         if (owns) {
             own_load(p, e, own);
-            own_inputs<RNG>(pk, e, 0, own, cur);
+            own_inputs<RNG>(pk, e, 0, own, cur, &pk);
             own_update<true>(pk, *pk.c, own, cur, rec0 + 3 * lane);           /* step 0 */
-            if (K > 1) own_inputs<RNG>(pk, e, 1, own, cur);
+            if (K > 1) own_inputs<RNG>(pk, e, 1, own, cur, &pk);
         }
         __syncthreads();
 #pragma unroll 1
@@ -2493,15 +2656,15 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
             float4* const rec_n = (k & 1) ? rec0 : rec1;
             if (owns && k + 1 < K) {
                 own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
-                if (k + 2 < K) own_inputs<RNG>(pk, e, k + 2, own, nxt);
+                if (k + 2 < K) own_inputs<RNG>(pk, e, k + 2, own, nxt, &pk);
             }
             __syncthreads();                                                   /* A: sweep k done */
             if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
                 own_reload(p, e, own);                                         /* env was reset in step k */
                 if (k + 1 < K) {
-                    if (p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 1, own, cur);   /* the policy sees the new episode */
+                    if (p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 1, own, cur, &pk);   /* the policy sees the new episode */
                     own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
-                    if (k + 2 < K && p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 2, own, nxt);
+                    if (k + 2 < K && p.many_policy >= 0) own_inputs<RNG>(pk, e, k + 2, own, nxt, &pk);
                 }
             }
             cur = nxt;
@@ -2526,7 +2689,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
     OwnIn oin;
     if (owns) {
         own_load(p, own_e, own);
-        own_inputs<RNG, OWNW>(pko, own_e, 0, own, oin);
+        own_inputs<RNG, OWNW>(pko, own_e, 0, own, oin, &pko);
     }
 #if UAM_STAMP
     unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2549,7 +2712,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         if constexpr (!OWNW) {
             if (owns) {
                 own_update<true>(pko, *pko.c, own, oin, rec0 + 3 * tid);
-                if (k + 1 < K) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin);    /* in flight while this step sweeps */
+                if (k + 1 < K) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin, &pko);    /* in flight while this step sweeps */
             }
             __syncthreads();
         }
@@ -2568,7 +2731,7 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
         if constexpr (!OWNW) {
             if (owns && ((const uint32_t*)(rec0 + 3 * tid))[3] == 0xFFFFFFFFu) {                             /* env was reset */
                 own_reload(p, own_e, own);
-                if (OWNW && k + 1 < K && p.many_policy >= 0) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin);
+                if (OWNW && k + 1 < K && p.many_policy >= 0) own_inputs<RNG, OWNW>(pko, own_e, k + 1, own, oin, &pko);
             }
         }
     }
@@ -2595,14 +2758,19 @@ __device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned cha
  * the COPY WAVE, that does all of it one step behind:
  *   sweeping waves   step k on registers; park raw positions (velocities when they changed) and the env's
  *                    (reward, done | info << 8) in LDS — two 16-byte LDS stores and one 8-byte one per lane and step
- *   ownship wave     one step AHEAD, as in the two-wave form (three record sets now: the copy wave still reads step
- *                    k's observation tail while step k + 2's record is being written)
+ *   ownship wave     AHEAD of the sweep: a whole batch of J = 64 / E steps per pass when the actions come from a tape
+ *                    (own_batch_pass: the ownship update is then off the step's critical path altogether), one step
+ *                    ahead as in the two-wave form when a built-in policy closes the loop inside the launch
  *   copy wave        one step BEHIND: after barrier B of step k it formats step k's rows from the parked state
  *                    (the same float32 operations as quad_obs, 16 B per lane, non-temporal) and stores the outputs
  * The lane-group width is a template parameter here (LC), with everything derived from it — group index, reduction
  * depth, row width, the copy wave's divisions — constant-folded: the kernel takes a by-value copy of the parameters
  * with those fields overwritten by constants.  The host picks this form only when the handle's geometry matches. */
-template <int MODE, bool ROS, int LC, int OBSC>
+/* KCO: the ownship wave's fp64 sincos literals pinned to scalar registers at their use (uam_pmath.h: ~100 scalar moves
+ * per ownship step) instead of hoisted into ~50 VGPRs for the whole loop.  Measured, the pinned flavour (127 VGPRs) is
+ * the faster one at every shape — 8192 x 32: 1.94 against 2.63 us per step, and 1.52 against 2.02 with the chip half
+ * empty (4096 x 32), so it is not a residency effect — and the only one the host instantiates. */
+template <int MODE, bool ROS, int LC, int OBSC, bool KCO>
 __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned char* lds_raw)
 {
     static_assert(LC >= 1 && LC <= 64 && (LC & (LC - 1)) == 0, "lane-group width: a power of two");
@@ -2614,12 +2782,22 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     p.knn = 0; p.track_ep = 0; p.shaped = 0; p.obs_direct = 0;
     const int K = p.many_K;
     const int T = (int)blockDim.x - 128;              /* sweeping threads; then the ownship wave, then the copy wave */
-    const int E = T >> LS;
-    p.E = E;
+    /* envs per block: at most T / L, and fewer where the host trades idle sweeping lanes for more blocks (small batches:
+     * more of the chip busy) and for more lanes per env in the ownship wave (a longer batch of steps per pass) */
+    const int E = p.E;
     const int tid = threadIdx.x;
-    float4* const rec = (float4*)lds_raw;             /* three sets of [E][3] float4 records */
-    uint2* const outb = (uint2*)(lds_raw + (size_t)E * 144);          /* two halves of [E] */
-    float* const slots = (float*)(lds_raw + (size_t)E * 160);         /* px, py, vx, vy: two halves of [T * 4] each */
+    /* the ownship wave gives every env J lanes (a batch of J steps per pass, own_batch_pass); the records of 2 J + 1 steps
+     * are live at most: the step the copy wave is formatting, the rest of the batch being swept, the batch computed ahead */
+    const int J = min(16, 64 / E), JS = 31 - __builtin_clz(J), ring = 2 * J + 1;
+    float4* const rec = (float4*)lds_raw;             /* ring of [E][3] float4 records, step k in slot k % ring */
+    uint2* const outb = (uint2*)(lds_raw + (size_t)ring * E * 48);              /* two halves of [E] */
+    float* const slots = (float*)(lds_raw + (size_t)ring * E * 48 + (size_t)E * 16);   /* px, py, vx, vy: two halves of [T * 4] each */
+    /* tape mode has ONE block barrier per step (A: sweep k done).  What the second one of the two-wave form ordered —
+     * the sweepers' next step behind the ownship wave's repair of a reset env's records — is a handshake here, paid only
+     * by a sweeping wave that reset an env: it waits until `ack` (steps whose resets the ownship wave has dealt with)
+     * has reached k + 1.  The in-launch policies keep barrier B (their ownship wave runs one step ahead only). */
+    uint32_t* const ack = (uint32_t*)(lds_raw + (size_t)ring * E * 48 + (size_t)E * 16 + (size_t)T * 128);
+    const bool two_bar = p.many_policy >= 0;
     const int SH4 = T * 4;
     float* const spx = slots; float* const spy = slots + 2 * SH4; float* const svx = slots + 4 * SH4; float* const svy = slots + 6 * SH4;
     const size_t slot_elems = (size_t)p.B * (size_t)DC;
@@ -2631,6 +2809,9 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         const int rows = min(E, p.B - env0);
         int slot = 0, r3 = 0;
         __syncthreads();
+#if UAM_STAMP
+        unsigned long long cw_work = 0, cw_wait = 0, cw_t = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
             float* obs_k = nullptr;
@@ -2638,11 +2819,17 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 if (p.obs_slots > 0) { obs_k = p.obs + (size_t)slot * slot_elems; slot = slot + 1 == p.obs_slots ? 0 : slot + 1; }
                 else if (k == K - 1) obs_k = p.obs;
             }
+#if UAM_STAMP
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cw_work += t_ - cw_t; cw_t = t_; }
+#endif
             __syncthreads();                                                   /* A: sweep k done */
-            __syncthreads();                                                   /* B */
+            if (two_bar) __syncthreads();                                      /* B */
+#if UAM_STAMP
+            { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cw_wait += t_ - cw_t; cw_t = t_; }
+#endif
             const int half = k & 1;
             const float4* const rec_k = rec + 3 * E * r3;
-            r3 = r3 == 2 ? 0 : r3 + 1;
+            r3 = r3 + 1 == ring ? 0 : r3 + 1;
             if (lane < rows) {
                 const uint2 o = outb[half * E + lane];
                 const size_t orow = (size_t)k * (size_t)p.B + (size_t)(env0 + lane);
@@ -2651,78 +2838,217 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 if (p.info) p.info[orow] = (uint8_t)(o.y >> 8);
             }
             if (obs_k) {
+                /* Slot i of the block (thread i / 4's intruder i % 4) is intruder i % NC of row i / NC: consecutive lanes
+                 * read consecutive LDS words and write consecutive 16-byte chunks of the rows (two tail chunks skipped
+                 * per row).  All reads of the step are issued before the first store. */
                 typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
                 uam_f32x4* const dst = (uam_f32x4*)(obs_k + (size_t)env0 * DC);
                 const float* const hx = spx + half * SH4; const float* const hy = spy + half * SH4;
                 const float* const hvx = svx + half * SH4; const float* const hvy = svy + half * SH4;
-                const int chunks = rows * CR;
-#pragma unroll 2
-                for (int c = lane; c < chunks; c += 64) {
-                    const int row = c / CR, col = c - row * CR;
-                    uam_f32x4 v;
-                    if (col < NC) {
-                        const int i = row * NC + col;
-                        const float x = hx[i], y = hy[i], vx = hvx[i], vy = hvy[i];
+                constexpr int JMAX = 8;                      /* T <= 128 (the host guarantees it): T / 16 slots per lane */
+                const int nj = T >> 4;
+                float x[JMAX], y[JMAX], vx[JMAX], vy[JMAX];
+#pragma unroll
+                for (int j = 0; j < JMAX; j++) {
+                    if (j < nj) { const int i = lane + 64 * j; x[j] = hx[i]; y[j] = hy[i]; vx[j] = hvx[i]; vy[j] = hvy[i]; }
+                }
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool has_tail = lane < 2 * rows;
+                if (has_tail) t = rec_k[3 * (lane >> 1) + 1 + (lane & 1)];
+#pragma unroll
+                for (int j = 0; j < JMAX; j++) {
+                    if (j < nj) {
+                        const int i = lane + 64 * j, row = i >> (LS + 2);
+                        uam_f32x4 v;
                         if constexpr (OBSC == UAM_OBS_NORM4) {      /* quad_obs, operation for operation */
-                            v.x = x * p.inv_W32; v.y = y * p.inv_H32;
-                            v.z = (vx + p.vmax32) * p.inv_vden32; v.w = (vy + p.vmax32) * p.inv_vden32;
-                        } else { v.x = x; v.y = y; v.z = vx; v.w = vy; }
-                    } else {
-                        const float4 t = rec_k[3 * row + 1 + (col - NC)];
-                        v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+                            v.x = x[j] * p.inv_W32; v.y = y[j] * p.inv_H32;
+                            v.z = (vx[j] + p.vmax32) * p.inv_vden32; v.w = (vy[j] + p.vmax32) * p.inv_vden32;
+                        } else { v.x = x[j]; v.y = y[j]; v.z = vx[j]; v.w = vy[j]; }
+                        if (row < rows) __builtin_nontemporal_store(v, &dst[i + 2 * row]);
                     }
-                    __builtin_nontemporal_store(v, &dst[c]);
+                }
+                if (has_tail) {
+                    uam_f32x4 v;
+                    v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+                    __builtin_nontemporal_store(v, &dst[(lane >> 1) * CR + NC + (lane & 1)]);
                 }
             }
         }
+#if UAM_STAMP
+        if (p.actions_out && lane == 0 && T == 64) {
+            unsigned long long* dst = (unsigned long long*)p.actions_out + (size_t)blockIdx.x * UAM_NSTAMP;
+            dst[12] = cw_work; dst[13] = cw_wait;
+        }
+#endif
         return;
     }
 
     if (tid >= T) {
-        /* ---------------- ownship wave (see sweep_many_body; record sets rotate over three) */
-        const UamParams& pk = *(const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        /* ---------------- ownship wave
+         * Everything this wave needs of the configuration is in registers before the loop: the parameters by value
+         * (with the compile-time geometry), the cold configuration as a private copy.  Read through the kernarg / cold
+         * pointers inside the loop instead, every use is a scalar load and a wait (27 waits a step: the ownship wave, not
+         * the sweep, then set the step time: 3100 of its 4100 cycles). */
+        const UamParams& pk = p;
+        const UamParams* const pka = (const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        OwnCold cl;
+        cl.load(p.c);
         const int lane = tid - T;
-        const int e = blockIdx.x * E + lane;
-        const bool owns = lane < E && e < p.B;
-        OwnRegs own;
-        OwnIn cur, nxt;
-        if (owns) {
-            own_load(p, e, own);
-            own_inputs<UAM_RNG_PHILOX>(pk, e, 0, own, cur);
-            own_update<true>(pk, *pk.c, own, cur, rec + 3 * lane);           /* step 0 */
-            if (K > 1) own_inputs<UAM_RNG_PHILOX>(pk, e, 1, own, cur);
-        }
-        __syncthreads();
-        int r3 = 0;
+#if UAM_STAMP
+        unsigned long long ow_work = 0, ow_wait = 0, ow_redo = 0, ow_resets = 0, ow_t = __builtin_amdgcn_s_memtime();
+#define UAM_OW_STAMP(acc) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc += t_ - ow_t; ow_t = t_; } while (0)
+#else
+#define UAM_OW_STAMP(acc) do { } while (0)
+#endif
+        if (p.many_policy < 0) {
+            /* ---- action tape: J steps per pass (own_batch_pass), lane = env-in-block * J + step-in-batch */
+            const int le = lane >> JS, j = lane & (J - 1);
+            const int e = blockIdx.x * E + le;
+            const bool on = le < E && e < p.B;
+            OwnRegs st;
+            st.ox = 0.f; st.oy = 0.f; st.hd = 0.0; st.sp = 0.0; st.gx = 0.0; st.gy = 0.0; st.vx = 0.0; st.vy = 0.0;
+            if (on) own_load(p, e, st);
+            if (lane == 0) *ack = 0u;
+            OwnIn bin, rin;
+            own_batch_fetch(pk, e, on, j, J, 0, 0, K, bin);
+            own_batch_pass<KCO>(pk, cl, bin, on, le, j, J, 0, 0, K, st, rec, E, ring, 0);
+            own_batch_fetch(pk, e, on, j, J, J, 0, K, bin);        /* the next batch's inputs, in flight until its pass */
+            int nb = 1, slot_nb = J;                 /* batches computed so far, ring slot of step nb * J */
+            int slot_k = 0, slot_b = 0;              /* ring slots of step k and of the first step of its batch */
+            int phase = 0;                           /* of the pass in progress for batch nb (0: none) */
+            OwnBatch w;
+            w.hd = 0.0; w.sp = 0.0; w.vx = 0.0; w.vy = 0.0; w.ox = 0.f; w.oy = 0.f;
+            __syncthreads();
 #pragma unroll 1
-        for (int k = 0; k < K; k++) {
-            float4* const rec_k = rec + 3 * E * r3;
-            r3 = r3 == 2 ? 0 : r3 + 1;
-            float4* const rec_n = rec + 3 * E * r3;
-            if (owns && k + 1 < K) {
-                own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
-                if (k + 2 < K) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt);
-            }
-            __syncthreads();                                                   /* A: sweep k done */
-            if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
-                own_reload(p, e, own);                                         /* env was reset in step k */
-                if (k + 1 < K) {
-                    if (p.many_policy >= 0) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 1, own, cur);   /* the policy sees the new episode */
-                    own_update<true>(pk, *pk.c, own, cur, rec_n + 3 * lane);
-                    if (k + 2 < K && p.many_policy >= 0) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt);
+            for (int k = 0; k < K; k++) {
+                const int b = k >> JS, jr = k & (J - 1);
+                if (jr == 0 && k > 0) slot_b = slot_k;
+                /* The next batch, from one step into the current one (the slots it overwrites held the batch before this
+                 * one, whose last record the copy wave read during the previous step): one phase per step's window
+                 * where the batch is long enough (J >= 4: windows 1, 2, 3), else the whole pass at once. */
+                const int jl = min(J, K - nb * J) - 1;
+                if (phase == 0 && jr == min(1, J - 1) && nb == b + 1 && nb * J < K) phase = 1;
+                if (phase == 1) {
+                    own_batch_p1a(pk, cl, bin, j, 0, jl, st, w);
+                    own_batch_p1b<KCO>(w);
+                    phase = 2;
+                    if (J < 4) {
+                        own_batch_p2a(j, 0, jl, st, w);
+                        own_batch_p2b(pk, cl, on && j <= jl, le, j, st, w, rec, E, ring, slot_nb);
+                        own_batch_p3(on, j, 0, jl, st, w);
+                        phase = 4;
+                    }
+                } else if (phase == 2) {
+                    own_batch_p2a(j, 0, jl, st, w);
+                    own_batch_p2b(pk, cl, on && j <= jl, le, j, st, w, rec, E, ring, slot_nb);
+                    phase = 3;
+                } else if (phase == 3) {
+                    own_batch_p3(on, j, 0, jl, st, w);
+                    phase = 4;
                 }
+                if (phase == 4) {
+                    nb++;
+                    slot_nb = slot_nb + J >= ring ? slot_nb + J - ring : slot_nb + J;
+                    own_batch_fetch(pk, e, on, j, J, nb * J, 0, K, bin);
+                    phase = 0;
+                }
+                UAM_OW_STAMP(ow_work);
+                __syncthreads();                                               /* A: sweep k done */
+                UAM_OW_STAMP(ow_wait);
+                const bool marked = on && ((const uint32_t*)(rec + 3 * E * slot_k + 3 * le))[3] == 0xFFFFFFFFu;
+                if (__ballot(marked)) {
+#if UAM_STAMP
+                    ow_resets++;
+#endif
+                    /* envs that were reset in step k: their later records were computed from the old episode.  A pass in
+                     * progress is finished first (from the state it started with), then redone for those envs. */
+                    if (phase != 0) {
+                        const int jl2 = min(J, K - nb * J) - 1;
+                        if (phase == 2) {
+                            own_batch_p2a(j, 0, jl2, st, w);
+                            own_batch_p2b(pk, cl, on && j <= jl2, le, j, st, w, rec, E, ring, slot_nb);
+                            phase = 3;
+                        }
+                        if (phase == 3) own_batch_p3(on, j, 0, jl2, st, w);
+                        nb++;
+                        slot_nb = slot_nb + J >= ring ? slot_nb + J - ring : slot_nb + J;
+                        own_batch_fetch(pk, e, on, j, J, nb * J, 0, K, bin);
+                        phase = 0;
+                    }
+                    if (marked) own_reload(p, e, st);
+                    if (jr + 1 < J && k + 1 < K) {
+                        own_batch_fetch(pk, e, marked, j, J, b * J, jr + 1, K, rin);
+                        own_batch_pass<KCO>(pk, cl, rin, marked, le, j, J, b * J, jr + 1, K, st, rec, E, ring, slot_b);
+                    }
+                    if (nb > b + 1 && (b + 1) * J < K) {
+                        const int sn = slot_b + J >= ring ? slot_b + J - ring : slot_b + J;
+                        own_batch_fetch(pk, e, marked, j, J, (b + 1) * J, 0, K, rin);
+                        own_batch_pass<KCO>(pk, cl, rin, marked, le, j, J, (b + 1) * J, 0, K, st, rec, E, ring, sn);
+                    }
+                    /* the records are in LDS before the sweeping wave that waits for them is released */
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(ack, (uint32_t)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                slot_k = slot_k + 1 == ring ? 0 : slot_k + 1;
+                UAM_OW_STAMP(ow_redo);
             }
-            cur = nxt;
-            __syncthreads();                                                   /* B: record k+1 final */
+            if (on && j == 0) own_store(p, e, st);
+        } else {
+            /* ---- built-in policy inside the launch: the action of step k + 1 depends on the state after step k, so the
+             * wave runs one step ahead only (sweep_many_body), lane = env-in-block */
+            const int e = blockIdx.x * E + lane;
+            const bool owns = lane < E && e < p.B;
+            OwnRegs own;
+            OwnIn cur, nxt;
+            if (owns) {
+                own_load(p, e, own);
+                own_inputs<UAM_RNG_PHILOX>(pk, e, 0, own, cur, pka);
+                own_update<KCO>(pk, cl, own, cur, rec + 3 * lane);           /* step 0 */
+                if (K > 1) own_inputs<UAM_RNG_PHILOX>(pk, e, 1, own, cur, pka);
+            }
+            __syncthreads();
+            int r3 = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                float4* const rec_k = rec + 3 * E * r3;
+                r3 = r3 + 1 == ring ? 0 : r3 + 1;
+                float4* const rec_n = rec + 3 * E * r3;
+                if (owns && k + 1 < K) {
+                    own_update<KCO>(pk, cl, own, cur, rec_n + 3 * lane);      /* step k+1, assuming no reset in step k */
+                    if (k + 2 < K) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt, pka);
+                }
+                UAM_OW_STAMP(ow_work);
+                __syncthreads();                                               /* A: sweep k done */
+                UAM_OW_STAMP(ow_wait);
+                if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
+                    own_reload(p, e, own);                                     /* env was reset in step k */
+                    if (k + 1 < K) {
+                        own_inputs<UAM_RNG_PHILOX>(pk, e, k + 1, own, cur, pka);   /* the policy sees the new episode */
+                        own_update<KCO>(pk, cl, own, cur, rec_n + 3 * lane);
+                        if (k + 2 < K) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt, pka);
+                    }
+                }
+                cur = nxt;
+                UAM_OW_STAMP(ow_work);
+                __syncthreads();                                               /* B: record k+1 final */
+                UAM_OW_STAMP(ow_wait);
+            }
+            if (owns) own_store(p, e, own);
         }
-        if (owns) own_store(p, e, own);
+#if UAM_STAMP
+        if (p.actions_out && lane == 0 && T == 64) {
+            unsigned long long* dst = (unsigned long long*)p.actions_out + (size_t)blockIdx.x * UAM_NSTAMP;
+            dst[10] = ow_work; dst[11] = ow_wait; dst[14] = ow_redo; dst[15] = ow_resets * 1000;
+        }
+#endif
+#undef UAM_OW_STAMP
         return;
     }
 
     /* ---------------- sweeping waves */
     const int g = tid >> LS, gl = tid & (LC - 1);
     const int env = blockIdx.x * E + g;
-    const bool quad_ok = env < p.B;
+    const bool quad_ok = env < p.B && g < E;
     const size_t base = (size_t)env * NC + 4u * gl;
     Quad<false, false> q;
     bool vel_dirty = false;
@@ -2730,7 +3056,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     quad_load<false, false>(p, base, quad_ok, q);
-    int32_t ncf = (env < p.B && gl == 0) ? p.s.no_conflict[env] : 0;
+    int32_t ncf = (quad_ok && gl == 0) ? p.s.no_conflict[env] : 0;
     __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0): see sweep_many_body */
     /* both halves of the velocity slots start out current */
     *(float4*)(svx + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
@@ -2740,30 +3066,42 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     OffBuf ob;
     ob.vel_prev = false;
     __syncthreads();
+    /* the sweeping wave is the step's critical path; the ownship and copy waves that share its SIMD fill the issue
+     * slots it leaves (VALU issue is arbitrated by priority, then age) */
+    __builtin_amdgcn_s_setprio(UAM_SWEEP_PRIO);
     int r3 = 0;
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
         float4* const rec_k = rec + 3 * E * r3;
-        r3 = r3 == 2 ? 0 : r3 + 1;
+        r3 = r3 + 1 == ring ? 0 : r3 + 1;
         const int half = k & 1;
         ob.px = spx + half * SH4; ob.py = spy + half * SH4; ob.vx = svx + half * SH4; ob.vy = svy + half * SH4;
         ob.out = outb + half * E;
+        ob.had_reset = false;
 #if UAM_STAMP
         sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob, stamp_acc);
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
-        __syncthreads();                                                       /* A */
-        __syncthreads();                                                       /* B */
-        stamp_acc[9] += __builtin_amdgcn_s_memtime() - tb;
 #else
         sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob);
+#endif
         __syncthreads();                                                       /* A */
-        __syncthreads();                                                       /* B */
+        if (two_bar) {
+            __syncthreads();                                                   /* B */
+        } else if (__ballot(ob.had_reset)) {
+            /* this wave reset an env: the ownship wave is redoing that env's records (rare: wait for its word) */
+            __builtin_amdgcn_s_setprio(0);
+            while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(k + 1)) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_s_setprio(UAM_SWEEP_PRIO);
+        }
+#if UAM_STAMP
+        stamp_acc[9] += __builtin_amdgcn_s_memtime() - tb;
 #endif
     }
 #if UAM_STAMP
     if (p.actions_out && (tid & 63) == 0) {
         unsigned long long* dst = (unsigned long long*)p.actions_out + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * UAM_NSTAMP;
-        for (int i = 0; i < UAM_NSTAMP; i++) dst[i] = stamp_acc[i];
+        for (int i = 0; i < 10; i++) dst[i] = stamp_acc[i];
     }
 #endif
     if (quad_ok) {
@@ -2771,14 +3109,16 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         if (vel_dirty) quad_store_vel<false, false>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
-    if (env < p.B && gl == 0) p.s.no_conflict[env] = ncf;
+    if (quad_ok && gl == 0) p.s.no_conflict[env] = ncf;
 }
 
-template <int MODE, bool ROS, int LC, int OBSC>
-__global__ void UAM_MANY_BOUNDS uam_sweep_many3_kernel(const UamParams p)
+/* held at four waves per SIMD (128 VGPRs): 16384 x 32 is 1024 blocks of four waves, exactly the chip's 4096 slots at that
+ * occupancy; the sweeping path needs ~115, what goes to scratch (a few dwords) belongs to the ownship wave's phase state */
+template <int MODE, bool ROS, int LC, int OBSC, bool KCO>
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) uam_sweep_many3_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    sweep_many3_body<MODE, ROS, LC, OBSC>(p, lds_raw);
+    sweep_many3_body<MODE, ROS, LC, OBSC, KCO>(p, lds_raw);
 }
 
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>

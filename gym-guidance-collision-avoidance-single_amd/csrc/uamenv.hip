@@ -47,6 +47,8 @@ struct uam_env {
     int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
     int many3_resident_blocks;  /* the same for the three-wave form (0: the handle's geometry has no such instance) */
+    int many3_kco;              /* (kept for the development override; only flavour 1 is instantiated) */
+    int Tm3, Em3;               /* three-wave form: sweeping threads and envs per block (Em3 <= Tm3 / L) */
     bool shared_stream;         /* UAM_RNG_MT19937_SHARED: cfg.rng_mode is normalised to UAM_RNG_MT19937, every env uses stream 0 */
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
@@ -86,8 +88,10 @@ static inline size_t lds_step(const uam_env* e, bool staged);
 static bool many_instance_exists(const uam_env* e);
 static UamSweepFn many4_fn(const uam_env* e);
 static inline size_t lds_many(const uam_env* e, int fl, bool staged);
-static UamSweepFn many3_fn(const uam_env* e);
+static UamSweepFn many3_fn(const uam_env* e, int kco = -1);
 static inline size_t lds_many3(const uam_env* e);
+static inline int grid_many(const uam_env* e, int fl);
+static inline int grid_many3(const uam_env* e);
 
 extern "C" const char* uam_last_error(void) { return g_err; }
 extern "C" const char* uam_version(void) { return "uamenv-hip 0.2 (gfx950, abi 2)"; }
@@ -462,6 +466,8 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->many_resident_blocks = 0;
     e->many4_resident_blocks = 0;
     e->many3_resident_blocks = 0;
+    e->many3_kco = 1;
+    e->Tm3 = 64; e->Em3 = 0;
     e->many_obs_direct = 0;
     if (!rc && many_instance_exists(e)) {
         int per_cu = 0;
@@ -472,11 +478,32 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many4_fn(e), e->T, lds_many(e, 2, true)) != hipSuccess) per_cu = 0;
             e->many4_resident_blocks = per_cu * e->num_cus;
         }
-        if (many3_fn(e)) {
-            per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e), e->Tm + 128, lds_many3(e)) != hipSuccess) per_cu = 0;
-            e->many3_resident_blocks = per_cu * e->num_cus;
+        {
+            /* three-wave form: envs per block.  The ownship wave gives every env 64 / E lanes = steps per pass, so fewer
+             * envs per block amortise its fp64 chain over more steps (and spread a small batch over more CUs), while more
+             * blocks share a SIMD between more waves: the smallest power of two >= 4 whose grid is still resident in one
+             * round, at most what the sweeping lanes hold; two sweeping waves per block only when one cannot take E envs */
+            const int emax = e->Tm / e->L;
+            e->Tm3 = 64; e->Em3 = 0;
+            int want = 4;
+            if (const char* k = getenv("UAMENV_MANY3_E")) want = atoi(k) > 0 ? atoi(k) : 4;      /* development override: minimum E */
+            for (int E3 = want; E3 <= emax && E3 <= 64; E3 <<= 1) {
+                e->Em3 = E3;
+                e->Tm3 = E3 * e->L > 64 ? E3 * e->L : 64;
+                if (!many3_fn(e, 1)) { e->Em3 = 0; break; }
+                per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e, 1), e->Tm3 + 128, lds_many3(e)) != hipSuccess) per_cu = 0;
+                e->many3_resident_blocks = per_cu * e->num_cus;
+                if (grid_many3(e) <= e->many3_resident_blocks) break;
+                e->Em3 = 0;
+            }
+            e->many3_kco = 1;
         }
+        if (getenv("UAMENV_DEBUG"))
+            fprintf(stderr, "[uamenv] looped kernel: grid %d, resident blocks: ownship-wave flavour %d, three-wave form %d (flavour %d), "
+                    "no-ownship-wave flavour %d; three-wave geometry: %d envs, %d sweeping threads per block, grid %d\n", grid_many(e, 1),
+                    e->many_resident_blocks, e->many3_resident_blocks, e->many3_kco, e->many4_resident_blocks, e->Em3, e->Tm3,
+                    e->Em3 ? grid_many3(e) : 0);
         if (const char* od = getenv("UAMENV_OBS_DIRECT")) e->many_obs_direct = atoi(od);   /* development override */
     }
     if (!rc && hipEventCreate(&e->ev0) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
@@ -662,28 +689,37 @@ static UamSweepFn many4_fn(const uam_env* e)
 /* the three-wave form (uam_sweep_many3_kernel: sweeping waves + ownship wave + copy wave, compile-time lane-group width):
  * plain step, full quads (N = 4 L, L a power of two), four floats per intruder in the observation */
 template <int LC>
-static UamSweepFn many3_fn_l(const uam_env* e)
+static UamSweepFn many3_fn_l(const uam_env* e, int kco)
 {
-    if (e->cfg.obs_mode == UAM_OBS_RAW4) return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_RAW4>;
-    return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_NORM4>;
+    (void)kco;        /* (only the flavour with the ownship literals pinned to SGPRs is instantiated: uam_device.h, KCO) */
+    if (e->cfg.obs_mode == UAM_OBS_RAW4) return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_RAW4, true>;
+    return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_NORM4, true>;
 }
-static UamSweepFn many3_fn(const uam_env* e)
+static UamSweepFn many3_fn(const uam_env* e, int kco)
 {
     if (!many_instance_exists(e) || e->cfg.dynamics == UAM_DYN_RANDINTRUDER || e->cfg.shaped_reward || e->hold_sh ||
         e->cfg.random_own_start || e->cfg.track_episodes)
         return nullptr;
     if (e->cfg.obs_mode != UAM_OBS_NORM4 && e->cfg.obs_mode != UAM_OBS_RAW4) return nullptr;
     if (e->cfg.num_intruders != 4 * e->L) return nullptr;          /* full quads, and Q = L */
+    if (e->Tm3 > 128 || e->Em3 < 1) return nullptr;                /* the copy wave holds T / 16 <= 8 slots per lane */
+    if (kco < 0) kco = e->many3_kco;
     switch (e->L) {
-    case 2: return many3_fn_l<2>(e);
-    case 4: return many3_fn_l<4>(e);
-    case 8: return many3_fn_l<8>(e);
-    case 16: return many3_fn_l<16>(e);
+    case 2: return many3_fn_l<2>(e, kco);
+    case 4: return many3_fn_l<4>(e, kco);
+    case 8: return many3_fn_l<8>(e, kco);
+    case 16: return many3_fn_l<16>(e, kco);
     default: return nullptr;
     }
 }
-/* LDS of one block: three record sets, two halves of the per-env outputs, two halves of the px / py / vx / vy slots */
-static inline size_t lds_many3(const uam_env* e) { return (size_t)e->Em * 160 + (size_t)e->Tm * 128; }
+/* LDS of one block: the record ring (2 J + 1 steps, J = min(16, 64 / E): sweep_many3_body), two halves of the per-env outputs,
+ * two halves of the px / py / vx / vy slots */
+static inline size_t lds_many3(const uam_env* e)
+{
+    const int J = 64 / e->Em3 < 16 ? (64 / e->Em3 > 0 ? 64 / e->Em3 : 1) : 16;
+    return (size_t)(2 * J + 1) * e->Em3 * 48 + (size_t)e->Em3 * 16 + (size_t)e->Tm3 * 128 + 16;      /* + the reset handshake word */
+}
+static inline int grid_many3(const uam_env* e) { return (e->cfg.num_envs + e->Em3 - 1) / e->Em3; }
 
 /* launch geometry of the looped kernel by flavour (1: ownship wave, 2: none) */
 static inline int many_E(const uam_env* e, int fl) { return fl == 2 ? e->E : e->Em; }
@@ -721,7 +757,7 @@ static int many_flavour(const uam_env* e)
  * extra wave per block, and the observation (if any) takes the 16-byte path */
 static bool use_many3(const uam_env* e, const UamParams& p, int fl)
 {
-    if (fl != 1 || !many3_fn(e) || grid_many(e, 1) > e->many3_resident_blocks) return false;
+    if (fl != 1 || e->Em3 < 1 || !many3_fn(e) || grid_many3(e) > e->many3_resident_blocks) return false;
     if (p.obs && !p.obs_vec) return false;
     if (const char* f = getenv("UAMENV_MANY3")) { if (!strcmp(f, "off")) return false; }   /* development override */
     return true;
@@ -733,11 +769,12 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
     p.E = many_E(e, fl);
     p.obs_direct = e->many_obs_direct;
     const bool m3 = use_many3(e, p, fl);
-    dim3 grid(grid_many(e, fl)), block(many_threads(e, fl) + (m3 ? 64 : 0));
+    if (m3) p.E = e->Em3;
+    dim3 grid(m3 ? grid_many3(e) : grid_many(e, fl)), block(m3 ? e->Tm3 + 128 : many_threads(e, fl));
     const size_t lds = m3 ? lds_many3(e) : lds_many(e, fl, p.obs_vec != 0);
 #if UAM_STAMP
     if (fl == 1) {   /* development build: per-phase s_memtime sums of every sweeping wave, averaged and printed per launch */
-        const int nw = grid_many(e, 1) * (e->Tm / 64);
+        const int nw = m3 ? grid_many3(e) * (e->Tm3 / 64) : grid_many(e, 1) * (e->Tm / 64);
         static unsigned long long* dbuf = nullptr; static int dcap = 0;
         if (dcap < nw) { if (dbuf) (void)hipFree(dbuf); (void)hipMalloc((void**)&dbuf, (size_t)nw * UAM_NSTAMP * 8); dcap = nw; }
         (void)hipMemsetAsync(dbuf, 0, (size_t)nw * UAM_NSTAMP * 8, st);
