@@ -224,6 +224,7 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
     info = torch.empty((K, B), dtype=torch.uint8, device=dev)
     ex = RolloutExchange(dist, K, counts, ctx.rank, dev, mode=args.exchange)
     looped = int(env.steps_per_launch(K)) > 1 and args.policy == "random"
+    kernel_name = "%s (one launch per %s)" % (env.rollout_kernel(K if looped else 1), "chunk" if looped else "step")
     acts = env.policy_actions("random") if args.policy == "goal" else None
     state = {"chunk": 0, "launches": 0}
     bound = {}
@@ -324,10 +325,7 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
            "value": float(sum(counts)) * steps / (median(reps_ms) * 1e-3),
            "ms_per_step": median(reps_ms) / steps,
            "steps_per_launch": (steps / launches[0]) if launches[0] else 0.0,
-           "kernel": ("uam_sweep_mt_many_kernel (one launch per chunk)" if args.rng == "mt19937" else
-                      "uam_sweep_heavy_many_kernel (one launch per chunk)" if args.precision == "exact" else
-                      "uam_sweep_many_kernel (one launch per chunk)") if looped
-                     else ("uam_sweep_mt_kernel (one launch per step)" if args.rng == "mt19937" else "uam_sweep_kernel (one launch per step)"),
+           "kernel": kernel_name,
            "stream_span_ms_per_step": median(span_ms) / steps, "launches": launches[0],
            "step_bytes": env.step_bytes, "obs_dim": env.obs_dim, "collectives_per_rank": ex.collectives,
            # algorithmic bytes of one launch: a step's bytes for the step kernel; for the looped kernel (state in
@@ -350,20 +348,33 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
 
 
 def copy_ms(torch, dev, nbytes, iters):
-    """A plain device copy that moves `nbytes` in total (half read, half written): the practical HBM ceiling."""
+    """Plain device copies that move `nbytes` in total (half read, half written): the practical HBM ceiling.  Two
+    kernels: the library's own hand-written copy (uam_bench_copy: one 16-byte element per thread, the float4 copy
+    MI355X_MICROARCH.md measures at 6.29 TB/s) and torch's copy kernel.  Returns (ms own, ms torch)."""
+    from uamenv import _capi as capi
     n = (nbytes // 2) // 16 * 16
     src = torch.empty((n,), dtype=torch.uint8, device=dev)
     dst = torch.empty((n,), dtype=torch.uint8, device=dev)
     src.zero_()
-    for _ in range(3):
-        dst.copy_(src)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        dst.copy_(src)
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    L = capi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for own in (True, False):
+        def once():
+            if own:
+                capi.check(L.uam_bench_copy(dev.index or 0, src.data_ptr(), dst.data_ptr(), n, st))
+            else:
+                dst.copy_(src)
+        for _ in range(3):
+            once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) / iters)
+    return out[0], out[1]
 
 
 def hbm_resident(ctx, args, variant):
@@ -418,10 +429,12 @@ def hbm_resident(ctx, args, variant):
     env.close()
     del tape, rew, done, info
     torch.cuda.empty_cache()
-    cms = copy_ms(torch, dev, nbytes, 10)
+    cms, cms_torch = copy_ms(torch, dev, nbytes, 10)
     ach = nbytes / (ms * 1e-3) / 1e9
     out = {"envs": B, "bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-           "copy_same_bytes_ms": cms, "frac_of_copy": cms / ms, "launches_timed": 320, "reps_ms": times,
+           "copy_same_bytes_ms": cms, "frac_of_copy": cms / ms, "copy_kernel": "uam_copy_flat_kernel (library: one 16-byte element per thread, grid as large as the buffer)",
+           "copy_frac_of_peak": nbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "torch_copy_same_bytes_ms": cms_torch,
+           "launches_timed": 320, "reps_ms": times,
            "note": "frac: hipEvents around 5 x 64 queued launches (stream span / launches: includes launch gaps and the "
                    "overlapped noise launches), median; kernel_frac: hipEvents around each of 64 launches (the step "
                    "kernel alone, what rocprofv3 reports); working set 1.1 GB state+obs, not cache-resident"}
@@ -562,7 +575,7 @@ def main():
             with open(pmc_path) as f:
                 traffic = json.load(f).get("uam_sweep_kernel", {}).get("hbm_bytes_per_launch")
             traffic_src = PMC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE in its own run; not measured in this invocation)"
-        ccopy = copy_ms(torch, torch.device("cuda", ctx.local_rank), int(bytes_per_launch), 50) if ctx.world == 1 else None
+        ccopy, ccopy_torch = copy_ms(torch, torch.device("cuda", ctx.local_rank), int(bytes_per_launch), 50) if ctx.world == 1 else (None, None)
         workloads = {"weak": "SingleAircraftEnv discrete-9, batch=%d envs x %d intruders per GPU (BASELINE.json configs[2], "
                              "roofline run)" % (args.batch, N),
                      "strong": "SingleAircraft2Env continuous, ONE batch of %d envs x %d intruders partitioned over the "
@@ -596,6 +609,7 @@ def main():
                                              % (" and stream waits on the collective" if ctx.world > 1 else ""),
                          "bracketed_launch_ms": res.get("bracketed_launch_ms"), "sampled_launches": res.get("sampled_launches"),
                          "copy_same_bytes_ms": ccopy, "frac_of_copy": (ccopy / launch_ms) if ccopy else None,
+                         "torch_copy_same_bytes_ms": ccopy_torch,
                          "hbm_resident": resident},
         }
         if sec is not None:

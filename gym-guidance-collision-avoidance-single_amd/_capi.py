@@ -111,6 +111,8 @@ SYMBOLS = [
     ("uam_rollout_policy", C.c_int, [_P, C.c_int32, C.c_int32, C.c_uint64, _P, C.c_int32, _P, _P, _P, _P, _P]),
     ("uam_steps_per_launch", C.c_int32, [_P, C.c_int32]),
     ("uam_policy_steps_per_launch", C.c_int32, [_P, C.c_int32]),
+    ("uam_rollout_kernel", C.c_char_p, [_P, C.c_int32]),
+    ("uam_bench_copy", C.c_int, [C.c_int, _P, _P, C.c_int64, _P]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
     ("uam_nearest", C.c_int, [_P, _P, _P]),

@@ -2852,9 +2852,11 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 for (int j = 0; j < JMAX; j++) {
                     if (j < nj) { const int i = lane + 64 * j; x[j] = hx[i]; y[j] = hy[i]; vx[j] = hvx[i]; vy[j] = hvy[i]; }
                 }
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                const bool has_tail = lane < 2 * rows;
+                /* the rows' two tail chunks: lane -> (row, half); a block of more than 32 envs takes two rounds */
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f), t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool has_tail = lane < 2 * rows, has_tail2 = lane + 64 < 2 * rows;
                 if (has_tail) t = rec_k[3 * (lane >> 1) + 1 + (lane & 1)];
+                if (has_tail2) t2 = rec_k[3 * ((lane + 64) >> 1) + 1 + (lane & 1)];
 #pragma unroll
                 for (int j = 0; j < JMAX; j++) {
                     if (j < nj) {
@@ -2871,6 +2873,11 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                     uam_f32x4 v;
                     v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
                     __builtin_nontemporal_store(v, &dst[(lane >> 1) * CR + NC + (lane & 1)]);
+                }
+                if (has_tail2) {
+                    uam_f32x4 v;
+                    v.x = t2.x; v.y = t2.y; v.z = t2.z; v.w = t2.w;
+                    __builtin_nontemporal_store(v, &dst[((lane + 64) >> 1) * CR + NC + (lane & 1)]);
                 }
             }
         }
@@ -3219,6 +3226,27 @@ __global__ void __launch_bounds__(256) uam_noise_kernel(const UamParams p, doubl
     double zh, zs;
     uam_philox_normals(p.gid0 + e, (p.env_step ? p.env_step[e] : base) + k, p.seed_lo, p.seed_hi, zh, zs);
     out[t] = make_double2(zh, zs);
+}
+
+/* the measuring stick of bench.py: a plain device copy, 16 bytes per lane, four loads in flight per lane, grid-stride over
+ * 2048 blocks of 256 threads (one round of the chip) — what the memory system delivers to the simplest possible kernel
+ * (MI355X_MICROARCH.md: 6.29 TB/s for this shape) */
+__global__ void __launch_bounds__(256) uam_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+/* (the same copy, one 16-byte element per thread and a grid as large as the buffer: uam_bench_copy's shape 1) */
+__global__ void __launch_bounds__(256) uam_copy_flat_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 /* built-in policies as a launch of their own (uam_policy): thread per env, state from HBM */

@@ -1130,6 +1130,25 @@ extern "C" int32_t uam_steps_per_launch(const uam_env* e, int32_t K)
     return (K > 1 && (many_supported(e) || mt_many_fn(e) || heavy_many_fn(e))) ? K : 1;
 }
 
+/* the kernel a tape-driven chunk of K steps runs in on this handle (observation buffer 16-byte aligned), for the labels
+ * of bench.py and the profiles: mirrors step_many_impl / launch_many */
+extern "C" const char* uam_rollout_kernel(const uam_env* e, int32_t K)
+{
+    if (!e || K < 1) return "";
+    if (K > 1 && mt_many_fn(e)) return "uam_sweep_mt_many_kernel";
+    if (K > 1 && heavy_many_fn(e)) return "uam_sweep_heavy_many_kernel";
+    if (K > 1 && many_supported(e)) {
+        const int fl = many_flavour(e);
+        if (fl == 2) return "uam_sweep_many4_kernel";
+        UamParams p;
+        memset(&p, 0, sizeof(p));
+        p.obs_vec = 1;
+        return use_many3(e, p, fl) ? "uam_sweep_many3_kernel" : "uam_sweep_many_kernel";
+    }
+    if (e->cfg.rng_mode == UAM_RNG_MT19937) return "uam_sweep_mt_kernel";
+    return e->cfg.precision == UAM_POS_EXACT ? "uam_sweep_heavy_kernel" : "uam_sweep_kernel";
+}
+
 /* uam_rollout_policy fuses a chunk only in the ownship-wave flavour of the looped kernel (step_many_impl) */
 extern "C" int32_t uam_policy_steps_per_launch(const uam_env* e, int32_t K)
 {
@@ -1277,6 +1296,29 @@ extern "C" int uam_policy(uam_env* e, int32_t kind, uint64_t policy_seed, void* 
     p.actions_out = actions_out;
     const int T = 256;
     hipLaunchKernelGGL(uam_policy_kernel, dim3((e->cfg.num_envs + T - 1) / T), dim3(T), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
+/* bench.py's copy ceiling (uamenv_bench.h) */
+extern "C" int uam_bench_copy(int device, const void* src_dev, void* dst_dev, int64_t nbytes, void* stream)
+{
+    if (!src_dev || !dst_dev || nbytes < 0) return fail(UAM_EINVAL, "NULL argument");
+    if ((((uintptr_t)src_dev | (uintptr_t)dst_dev) & 15u) || (nbytes & 15)) return fail(UAM_EINVAL, "uam_bench_copy needs 16-byte aligned buffers and size");
+    if (nbytes == 0) return UAM_OK;
+    HIP_TRY(hipSetDevice(device));
+    const size_t n16 = (size_t)nbytes / 16;
+    /* one 16-byte element per thread, a grid as large as the buffer: 6.26 TB/s at 1.5 GB on MI355X (the guide's float4-copy
+     * figure); grid-stride forms, whose threads touch addresses megabytes apart, measure 4.3-5.1 TB/s (tools/bench_copy.py) */
+    int shape = 1;
+    if (const char* sh = getenv("UAMENV_COPY_SHAPE")) shape = atoi(sh);      /* development: 0 grid-stride x4 over 2048 blocks, 1 flat, N > 1 grid-stride over N blocks */
+    if (shape == 1) {
+        hipLaunchKernelGGL(uam_copy_flat_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)dst_dev, n16);
+    } else {
+        const size_t cap = shape > 1 ? (size_t)shape : 2048;
+        const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, cap);
+        hipLaunchKernelGGL(uam_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)dst_dev, n16);
+    }
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }

@@ -411,6 +411,10 @@ class BatchedSingleAircraftEnv:
         """K if a tape-driven chunk of K steps (step_many / rollout_into) runs as one launch on this handle, else 1."""
         return int(self._lib.uam_steps_per_launch(self._h, int(K)))
 
+    def rollout_kernel(self, K):
+        """Name of the kernel a tape-driven chunk of K steps runs in on this handle (labels of bench lines / profiles)."""
+        return self._lib.uam_rollout_kernel(self._h, int(K)).decode()
+
     def policy_steps_per_launch(self, K):
         """The same for rollout_policy: K only where the policy is evaluated inside the looped kernel's launch."""
         return int(self._lib.uam_policy_steps_per_launch(self._h, int(K)))

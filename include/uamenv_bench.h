@@ -47,6 +47,16 @@ int uam_kernel_timing_read(uam_env* env, void* stream, float* own_ms_out, float*
  * round); 0 on a bad argument.  uam_steps_per_launch (uamenv.h) answers the same question for action tapes. */
 int32_t uam_policy_steps_per_launch(const uam_env* env, int32_t K);
 
+/* A plain device-to-device copy of nbytes (16-byte aligned pointers and size) by a hand-written kernel: one 16-byte element
+ * per thread, 256-thread blocks, a grid as large as the buffer (6.26 TB/s at 1.5 GB on MI355X).  bench.py times it over the same number of
+ * bytes a step moves (half read, half written) as the practical ceiling of the memory system next to the 8 TB/s peak. */
+int uam_bench_copy(int device, const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);
+
+/* Name of the kernel a tape-driven chunk of K steps (uam_step_many / uam_rollout) runs in on this handle — the single-step
+ * kernel when K launches are queued, else the K-steps-per-launch form picked for the handle's mode and batch size.  A
+ * static string; "" on a bad argument.  For labels in bench lines and profiles. */
+const char* uam_rollout_kernel(const uam_env* env, int32_t K);
+
 #ifdef __cplusplus
 }
 #endif

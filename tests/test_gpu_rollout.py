@@ -29,6 +29,11 @@ def uamenv():
     ("discrete9", 65536, 32, 4, 2, True),      # grid larger than one resident round: the looped kernel in two rounds
     ("randintruder", 65536, 16, 3, 1, False),  # ... for the plain step only: this one queues K single-step launches
     ("discrete9", 300, 5, 6, 6, True),         # D = 28: 16-byte aligned rows only every 4th env
+    # the three-wave form (sweeping + ownship + copy wave, uam_sweep_many3_kernel) in its other geometries
+    ("mcts", 2048, 16, 21, 3, True),           # raw 4-wide rows, pair actions; 4 envs per block, 16 steps per ownship pass
+    ("continuous", 16384, 32, 11, 2, True),    # two sweeping waves per block, 4 steps per ownship pass
+    ("discrete9", 65536, 8, 5, 1, True),       # 64 envs per block: one step per ownship pass
+    ("continuous2", 1000, 64, 19, 19, True),   # partial last block, K not a multiple of the pass length
 ])
 def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     """Slot k % R of the rollout's obs buffer must hold exactly what uam_step would have returned at step k, and
@@ -39,6 +44,9 @@ def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     a.reset(); b.reset()
     dev = a.device
     assert (a.steps_per_launch(K) == K) == looped, "unexpected launch form"
+    if variant in ("mcts", "continuous2") or (variant, B) in (("continuous", 16384), ("discrete9", 65536), ("continuous", 8192), ("discrete9", 4096)):
+        want_kernel = "uam_sweep_many4_kernel" if (variant, B, N) == ("discrete9", 65536, 32) else "uam_sweep_many3_kernel"
+        assert a.rollout_kernel(K) == want_kernel, a.rollout_kernel(K)
     for rep in range(2):
         tape = torch.stack([a.policy_actions("goal" if rep else "random", seed=rep * 50 + k) for k in range(K)]).contiguous()
         obs = torch.full((R, B, a.obs_dim), float("nan"), dtype=torch.float32, device=dev)

@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""Development tool: what a plain device copy achieves at the sweep kernel's footprint (context for roofline.frac).
-Traffic = read + write bytes; sizes chosen to match one batched step at 65536x32 (94 MB) and at 1M x 32 (1.5 GB)."""
-import json, torch
-for total_mb in (94, 375, 1500):
-    n = total_mb * 1000 * 1000 // 8          # float32 elements per side (read n*4 + write n*4)
-    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
-    b = torch.empty_like(a)
-    for _ in range(20):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 200
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
-    print(json.dumps({"copy_traffic_MB": total_mb, "us": round(us, 2), "GBps": round(n * 8 / us / 1e3, 1)}))
-    del a, b
+"""Development tool: the library's copy kernel (uam_bench_copy) in its shapes against torch's copy, at the sizes bench.py
+uses it (94 MB and 1.5 GB moved per copy: half read, half written)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from uamenv import _capi as capi
+L = capi.lib()
+dev = torch.device("cuda", 0)
+for total in (93716480, 1499463680):
+    n = (total // 2) // 16 * 16
+    src = torch.zeros((n,), dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+    for shape in ("torch", "0", "1", "512", "1024", "4096", "8192", "16384"):
+        if shape != "torch":
+            os.environ["UAMENV_COPY_SHAPE"] = shape
+        f = (lambda: dst.copy_(src)) if shape == "torch" else (lambda: capi.check(L.uam_bench_copy(0, src.data_ptr(), dst.data_ptr(), n, st)))
+        for _ in range(5): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30): f()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 30
+        print("moved %.0f MB shape %-6s %.4f ms  %.2f TB/s" % (2 * n / 1e6, shape, ms, 2 * n / ms / 1e9))
