@@ -9,17 +9,17 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-secondary --no-cpu-baseline > $OUT/bench_primary_under_rocprof.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-build --sustain-seconds 0 --no-secondary --no-cpu-baseline > $OUT/bench_primary_under_rocprof.json 2> $OUT/trace.log
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
 echo "trace 1 done"
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_all -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_default_under_rocprof.json 2> $OUT/trace_all.log
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_all -- python3 $R/bench.py --no-build --sustain-seconds 0 --no-cpu-baseline > $OUT/bench_default_under_rocprof.json 2> $OUT/trace_all.log
 echo "trace 2 done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 60 --warmup 20 --reps 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --no-build --sustain-seconds 0 --steps 60 --warmup 20 --reps 2 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
   echo "pmc $c done"
 done
 cd $R
@@ -53,7 +53,7 @@ out["_note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half
                 "--kernel-trace only; Infinity-Cache hits are counted")
 # the entry bench.py reads: the step kernel at the headline grid (65536 envs x 8 lanes)
 for key, v in list(out.items()):
-    if key.startswith("uam_sweep_kernel<false, 0, 0, false, false> grid=%d" % (65536 * 8)):
+    if key.startswith("uam_sweep_kernel<false, 0, 0, false, false> grid=%d" % (65536 * 8)) and "uam_sweep_kernel" not in out:
         out["uam_sweep_kernel"] = v
 json.dump(out, open("$OUT/pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
