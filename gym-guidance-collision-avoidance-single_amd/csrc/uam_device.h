@@ -308,7 +308,7 @@ __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
 typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32W;
 template <int U = 4>
 __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, const int gen, const int len, const int gl,
-                                              const int L, UAM_LDS_U32W win, unsigned long long* dbg = nullptr)
+                                              const int L, UAM_LDS_U32W win, unsigned long long* dbg = nullptr, const bool dry = false)
 {
     /* BRANCH-FREE inside a chunk: with `if (k >= gen) { twist; store }` the value of word k reached the LDS write from
      * two paths (loaded / computed), and at that merge the compiler waits for vmcnt(0) — on the computed path that is
@@ -340,7 +340,7 @@ __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, cons
             const uint32_t vt = c[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             const uint32_t v = k >= gen ? vt : a[u];
             if (i < len) {
-                key[k] = v;
+                if (!dry) key[k] = v;          /* (dry: the code-warming run of mt_epilogue_fn leaves the stream alone) */
                 win[i] = mt_temper(v);
             }
         }
@@ -1226,11 +1226,11 @@ __device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int e
 /* the tail of reset(): the per-env fields (lane 0 of the group) and the obs tail of the new episode */
 __device__ __forceinline__ void reset_finish(const UamParams& p, int env, int gl, uint32_t rc, float oxf, float oyf, double ohd,
                                              double osp, double ovx, double ovy, double gx, double gy, float* tail,
-                                             float& rox, float& roy)
+                                             float& rox, float& roy, const bool dry = false)
 {
     /* every lane of the group has read reset_count; the group is one wave-resident unit */
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0) {
+    if (gl == 0 && !dry) {
         p.s.own_x[env] = oxf; p.s.own_y[env] = oyf;
         p.s.own_h[env] = ohd; p.s.own_s[env] = osp;
         p.s.own_vx[env] = ovx; p.s.own_vy[env] = ovy;
@@ -1432,7 +1432,7 @@ __device__ __forceinline__ int mt_quad_from_buffer(const UamParams& p, const UAM
 template <bool POS64, bool SH, bool ROS, bool KC>
 __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool need, const int env, const int gl, const int L,
                                               const bool quad_ok, MtWin& m, Quad<POS64, SH>& q, float* tail, float& rox,
-                                              float& roy, uint32_t* lds, unsigned long long* st = nullptr)
+                                              float& roy, uint32_t* lds, unsigned long long* st = nullptr, const bool dry = false)
 {
 #if UAM_STAMP
     unsigned long long rs_last = __builtin_amdgcn_s_memtime();
@@ -1475,9 +1475,9 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
             for (int part = 0; part < 2; part++) {      /* (one body for both parts: code bytes) */
                 const int plen = part ? len2 : len1;
 #if UAM_STAMP
-                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), st + 4);
+                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), st + 4, dry);
 #else
-                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0));
+                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), nullptr, dry);
 #endif
             }
             UAM_RSTAMP(3);
@@ -1561,11 +1561,20 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
             /* the goal was drawn by the last quad's lane */
             const int gsrc = (lane - gl) + (Q - 1);
             gx = __shfl(gx, gsrc); gy = __shfl(gy, gsrc);
-            reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy);
+            reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy, dry);
         }
     }
 }
 
+/* MODE bits: 1 RandIntruder dynamics, 2 reward shaped by the nearest swept intruder, 4 k-nearest observation */
+#define UAM_MODE_RI 1
+#define UAM_MODE_SHAPED 2
+#define UAM_MODE_KNN 4
+/* (Tried in round 3 and removed: the reset epilogue as an out-of-line function, so that the first wave of a few hundred
+ * blocks could run it DRY at the head of the launch and pull its ~6 KB of code into the instruction cache where a
+ * straggler is free.  A kernel that calls carries the callee's register saves as scratch (256 B per lane), and any
+ * private segment costs every wave of the launch: 52 -> 64 us per step with the call alone, 67-73 with the warm-up
+ * waves on top.  profiles/r03_mt_mode.md.) */
 /* ------------------------------------------------------------------ built-in device-side policies
  * Functions of the ownship / goal state only, so the looped kernel's ownship wave can evaluate them itself and close
  * the loop inside a launch (uam_rollout_policy); uam_policy_kernel evaluates the same function from HBM state.
@@ -1925,8 +1934,16 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
     const uint32_t w0 = aw[i0], w1 = aw[is_pair ? i0 + 1 : i0];
     const int ai0 = (int)w0, ai1 = (int)w1;
     const float af = __uint_as_float(w0);
-    const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
-    const double zh = z.x, zs = z.y;
+    double zh, zs;
+    if (p.noise) {
+        const double2 z = p.noise[(size_t)k * (size_t)p.B + e];   /* drawn ahead by uam_noise_kernel */
+        zh = z.x; zs = z.y;
+    } else {
+        /* graph-safe handles with a small grid: the thread draws its two normals itself (the same function of the same
+         * counters the noise kernel evaluates) — one launch per step instead of two, when a launch boundary costs
+         * more than this fp64 chain in front of the block's barrier */
+        uam_philox_normals(p.gid0 + (uint32_t)e, uam_step_of(p, e, k), p.seed_lo, p.seed_hi, zh, zs);
+    }
     double a0, a1;
     bool has_speed = true;
     if (p.action_mode == UAM_ACT_DISCRETE9) { a0 = (double)(ai0 / 3); a1 = (double)(ai0 % 3); }   /* :128-131 */
@@ -1984,10 +2001,6 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
  * records over through LDS, and one block barrier later everyone sweeps (a separate ownship launch cost
  * 5.5 us of pure latency at B=65536).  The threads that run the ownship phase fetch their quad after it, so
  * the phase never adds register pressure. */
-/* MODE bits: 1 RandIntruder dynamics, 2 reward shaped by the nearest swept intruder, 4 k-nearest observation */
-#define UAM_MODE_RI 1
-#define UAM_MODE_SHAPED 2
-#define UAM_MODE_KNN 4
 /* one step of the sweep for this block.  k = step within the launch (0 for uam_sweep_kernel; the loop index of
  * uam_sweep_many_kernel): the Philox step counter, the action / noise / reward / done / info rows advance with it;
  * obs_k = where this step emits its observation (nullptr: it does not). */

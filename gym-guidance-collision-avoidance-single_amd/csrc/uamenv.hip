@@ -912,10 +912,19 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
     p.actions = actions; p.obs = obs_out; p.reward = reward_out; p.done = done_out; p.info = info_out;
     if (e->env_step) {
         /* graph-safe: the noise of THIS step, keyed by the per-env counters in device memory; nothing in either
-         * launch's arguments depends on how many steps have run */
-        hipLaunchKernelGGL(uam_noise_kernel, dim3((unsigned)((e->cfg.num_envs + 255) / 256)), dim3(256), 0, st, p, e->noise, 0u, 1);
-        HIP_TRY(hipGetLastError());
-        p.noise = e->noise;
+         * launch's arguments depends on how many steps have run.  A small grid (at most two blocks per CU: the step is
+         * latency-bound, a launch boundary costs more than an fp64 chain in front of the block's barrier) draws it
+         * inside the step kernel's ownship phase — one launch per step; a large one keeps the separate launch, which
+         * takes the draw off the step's critical path */
+        bool inline_noise = grid_of(e) <= 2 * e->num_cus && !e->shared_stream;
+        if (const char* v = getenv("UAMENV_INLINE_NOISE")) inline_noise = atoi(v) != 0;      /* development override */
+        if (inline_noise) {
+            p.noise = nullptr;
+        } else {
+            hipLaunchKernelGGL(uam_noise_kernel, dim3((unsigned)((e->cfg.num_envs + 255) / 256)), dim3(256), 0, st, p, e->noise, 0u, 1);
+            HIP_TRY(hipGetLastError());
+            p.noise = e->noise;
+        }
         p.step_index = 0;
     } else if (e->cfg.rng_mode == UAM_RNG_PHILOX) {
         /* ownship noise of the next NOISE_AHEAD steps in one lane-parallel launch (counter-based: the same
