@@ -2636,9 +2636,22 @@ __global__ void UAM_STEP_BOUNDS uam_sweep_kernel(const UamParams p)
  * !OWNW = a shard that needs every wave slot of the chip for its sweeping waves (32768 x 32: 16 waves per CU) has
  * no room for ownship waves: threads tid < E of the sweeping waves run the ownship phase at the head of each step,
  * as in the single-step kernel, with their registers persistent too. */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool OWNW>
-__device__ __forceinline__ void sweep_many_body(const UamParams& p, unsigned char* lds_raw)
+/* LC > 0 (the flavour without ownship wave only): the lane-group width as a template parameter — full quads, N = 4 LC,
+ * normalised observation on the 16-byte path — with everything derived from it constant-folded through a by-value copy of
+ * the parameters (as in sweep_many3_body): fewer instructions and scalar registers for the shard that needs every wave
+ * slot of the chip (32768 x 32) */
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool OWNW, int LC = 0>
+__device__ __forceinline__ void sweep_many_body(const UamParams& p_in, unsigned char* lds_raw)
 {
+    UamParams p_spec = p_in;
+    if constexpr (LC > 0) {
+        static_assert(!OWNW && !SH && MODE == 0 && !POS64, "the specialised form exists for the plain float32 step without ownship wave");
+        constexpr int LS_ = LC == 1 ? 0 : LC == 2 ? 1 : LC == 4 ? 2 : LC == 8 ? 3 : LC == 16 ? 4 : LC == 32 ? 5 : 6;
+        p_spec.L = LC; p_spec.lshift = LS_; p_spec.Q = LC; p_spec.N = 4 * LC; p_spec.Np = 4 * LC; p_spec.D = 16 * LC + 8;
+        p_spec.obs_w = 4; p_spec.obs_vec = 1; p_spec.obs_mode = UAM_OBS_NORM4; p_spec.knn = 0; p_spec.track_ep = 0; p_spec.shaped = 0;
+        p_spec.obs_direct = 0;
+    }
+    const UamParams& p = LC > 0 ? p_spec : p_in;
     const int K = p.many_K;
     const int T = (int)blockDim.x - (OWNW ? 64 : 0);  /* sweeping threads; with OWNW the last wave is the ownship wave */
     const int tid = threadIdx.x;
@@ -3150,11 +3163,11 @@ __global__ void UAM_MANY_BOUNDS uam_sweep_many_kernel(const UamParams p)
 
 /* the flavour without ownship wave, held at 4 waves/SIMD (128 VGPRs, a few spills) so that 16 sweeping waves per CU
  * are resident: 1024 blocks of 256 threads = 32768 envs x 32 intruders in one round */
-template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
+template <bool POS64, int RNG, int MODE, bool SH, bool ROS, int LC = 0>
 __global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) uam_sweep_many4_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    sweep_many_body<POS64, RNG, MODE, SH, ROS, false>(p, lds_raw);
+    sweep_many_body<POS64, RNG, MODE, SH, ROS, false, LC>(p, lds_raw);
 }
 
 /* reset kernel: uam_reset (all envs or mask).  LDS: E*D floats of obs staging (aligned obs only). */

@@ -721,6 +721,21 @@ static inline size_t lds_many3(const uam_env* e)
 }
 static inline int grid_many3(const uam_env* e) { return (e->cfg.num_envs + e->Em3 - 1) / e->Em3; }
 
+/* the same with the lane-group width a template parameter (full quads, normalised observation on the 16-byte path,
+ * discrete-9 / continuous step): N = 16, 32 or 64 */
+static UamSweepFn many4_spec_fn(const uam_env* e)
+{
+    if (!many4_fn(e) || e->cfg.random_own_start || e->cfg.track_episodes || e->cfg.obs_mode != UAM_OBS_NORM4 ||
+        e->cfg.num_intruders != 4 * e->L)
+        return nullptr;
+    switch (e->L) {
+    case 4: return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, false, 4>;
+    case 8: return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, false, 8>;
+    case 16: return uam_sweep_many4_kernel<false, UAM_RNG_PHILOX, 0, false, false, 16>;
+    default: return nullptr;
+    }
+}
+
 /* launch geometry of the looped kernel by flavour (1: ownship wave, 2: none) */
 static inline int many_E(const uam_env* e, int fl) { return fl == 2 ? e->E : e->Em; }
 static inline int many_threads(const uam_env* e, int fl) { return fl == 2 ? e->T : e->Tm + 64; }
@@ -792,7 +807,9 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
         return;
     }
 #endif
-    hipLaunchKernelGGL(fl == 2 ? many4_fn(e) : (m3 ? many3_fn(e) : many_fn(e)), grid, block, lds, st, p);
+    UamSweepFn fn4 = many4_fn(e);
+    if (fl == 2 && many4_spec_fn(e) && (!p.obs || p.obs_vec) && !getenv("UAMENV_MANY4_GENERIC")) fn4 = many4_spec_fn(e);
+    hipLaunchKernelGGL(fl == 2 ? fn4 : (m3 ? many3_fn(e) : many_fn(e)), grid, block, lds, st, p);
 }
 
 static bool many_supported(const uam_env* e) { return many_flavour(e) != 0; }
