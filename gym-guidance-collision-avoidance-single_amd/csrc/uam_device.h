@@ -47,6 +47,9 @@
 #ifndef UAM_STAMP
 #define UAM_STAMP 0
 #endif
+#ifndef UAM_OWN_SPLIT_J
+#define UAM_OWN_SPLIT_J 8        /* ownship batches of at least this many steps spread their pass over four windows instead of three */
+#endif
 #ifndef UAM_SWEEP_PRIO
 #define UAM_SWEEP_PRIO 3      /* s_setprio of the sweeping waves of the three-wave looped kernel */
 #endif
@@ -65,6 +68,12 @@
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local"); } while (0)
 #define UAM_WAVE_LDS_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local"); \
     __builtin_amdgcn_wave_barrier(); } while (0)
+/* Block barrier of the three-wave looped kernel: everything its waves hand each other goes through LDS, so the barrier
+ * orders LDS only.  __syncthreads() also waits for vmcnt(0) — for the copy wave that is the completion of the observation
+ * rows it has just stored (nobody in the block reads them), for the ownship wave the action / noise loads it prefetched
+ * for the next batch. */
+#define UAM_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define UAM_MT_N 624
 #define UAM_MT_M 397
 #define UAM_MAX_BLOCK 512
@@ -760,21 +769,48 @@ __device__ __forceinline__ void grp_reduce_pair(T& k, uint32_t& i, int L, Better
 #undef UAM_PAIR_STEP
 }
 
+/* The 32-bit integer reductions of the sweep (first NMAC index, packed conflict counts): one DPP-modified VALU instruction
+ * per butterfly level, v = op(perm(v), v), instead of the copy + hazard nop + v_mov_dpp + op the compiler emits for the
+ * generic form (it does not fold the permutation into the consumer).  s_nop 1: a DPP operand written by the previous VALU
+ * instruction needs two wait states.  A lane whose source lane is switched off keeps its own value, as in the generic form. */
+#define UAM_DPP_OP(NAME, OPC)                                                                                                    \
+    __device__ __forceinline__ uint32_t NAME(uint32_t v, int L)                                                                  \
+    {                                                                                                                            \
+        if (L >= 2) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));      \
+        if (L >= 4) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));      \
+        if (L >= 8) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));          \
+        if (L >= 16) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));              \
+        return v;                                                                                                                \
+    }
+UAM_DPP_OP(grp16_min, "v_min_u32_dpp")
+UAM_DPP_OP(grp16_max, "v_max_u32_dpp")
+UAM_DPP_OP(grp16_add, "v_add_u32_dpp")
+UAM_DPP_OP(grp16_or, "v_or_b32_dpp")
+#undef UAM_DPP_OP
+
 __device__ __forceinline__ uint32_t grp_min(uint32_t v, int L)
 {
-    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return min(a, b); });
+    v = grp16_min(v, L);
+    for (int o = 16; o < L; o <<= 1) v = min(v, lane_xor(v, o));
+    return v;
 }
 __device__ __forceinline__ uint32_t grp_max(uint32_t v, int L)
 {
-    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return max(a, b); });
+    v = grp16_max(v, L);
+    for (int o = 16; o < L; o <<= 1) v = max(v, lane_xor(v, o));
+    return v;
 }
 __device__ __forceinline__ uint32_t grp_add(uint32_t v, int L)
 {
-    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return a + b; });
+    v = grp16_add(v, L);
+    for (int o = 16; o < L; o <<= 1) v = v + lane_xor(v, o);
+    return v;
 }
 __device__ __forceinline__ uint32_t grp_or(uint32_t v, int L)
 {
-    return grp_reduce(v, L, [](uint32_t a, uint32_t b) { return a | b; });
+    v = grp16_or(v, L);
+    for (int o = 16; o < L; o <<= 1) v = v | lane_xor(v, o);
+    return v;
 }
 
 /* np.linalg.norm(own - intruder) < thr, SingleAircraftEnv.py:312-313 + NEP-50 compare.
@@ -855,7 +891,9 @@ __device__ __forceinline__ void spawn_velocity(double sp, double hd, float& vx, 
  * LEAN (float32 positions, Philox, speed/heading not held): the whole spawn is float32 arithmetic
  * on the Philox words — x, y, speed with 24 random bits, heading with 26 via the quadrant sincos —
  * so the sweep kernel carries no fp64 trig.  Otherwise the reference's float64 construction. */
-template <bool POS64, int RNG, bool LEAN, bool KC = false>
+/* WIDE (lean Philox spawn only): the 64-bit-product Philox (half the quarter-rate multiplies, more registers) — the looped
+ * kernels at one or two waves per SIMD have the registers and pay the respawn pass on nearly every step */
+template <bool POS64, int RNG, bool LEAN, bool KC = false, bool WIDE = false>
 __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_t idx, bool reset_phase, float ox,
                                       float oy, typename PosT<POS64>::type& X, typename PosT<POS64>::type& Y,
                                       bool& prom, float& vx, float& vy, double& sp, double& hd)
@@ -864,7 +902,7 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
     const uint32_t purpose = reset_phase ? UAM_PH_RESET_SPAWN : UAM_PH_SPAWN;
     if constexpr (LEAN) {
         uint32_t w[4];
-        rng.block(reset_phase, purpose, idx, 0, w);
+        if constexpr (WIDE) rng.block_wide(reset_phase, purpose, idx, 0, w); else rng.block(reset_phase, purpose, idx, 0, w);
         float fx = (float)(w[0] >> 8) * p.spawn_sx, fy = (float)(w[1] >> 8) * p.spawn_sy;
         const float u = (float)(w[2] >> 8) * 0x1p-24f;
         const float spf = p.min_speed32 + p.vrange32 * u;
@@ -877,7 +915,7 @@ __device__ inline void spawn_intruder(const UamParams& p, Rng<RNG>& rng, uint32_
         uint32_t attempt = 0;
         while (too_close<POS64>(ox, oy, (P)fx, (P)fy, false, p)) {
             attempt++;
-            rng.block(reset_phase, purpose, idx, attempt, w);
+            if constexpr (WIDE) rng.block_wide(reset_phase, purpose, idx, attempt, w); else rng.block(reset_phase, purpose, idx, attempt, w);
             fx = (float)(w[0] >> 8) * p.spawn_sx;
             fy = (float)(w[1] >> 8) * p.spawn_sy;
         }
@@ -2017,6 +2055,8 @@ struct OffBuf {
     uint2* out;                                    /* this step's half of the block's [E] (reward bits, done | info << 8) */
     bool vel_prev;                                 /* some velocity of my quad changed in the previous step */
     bool had_reset;                                /* out: my env was reset in this step (its later ownship records are being redone) */
+    float4 s0;                                     /* in: the first float4 of my env's record of THIS step, read ahead of the */
+    bool have_s0;                                  /*     previous step's barrier (false: read it now) */
 };
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false, bool OFFL = false>
 __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k,
@@ -2108,7 +2148,15 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
         if (env_first >= p.B) return;                /* whole wave past the batch end */
     }
     const float4* shp = (const float4*)(lds_share + 3 * (env_ok ? g : wave_first_g));
-    const float4 s0 = shp[0];              /* same address for the whole lane group: one broadcast load */
+    float4 s0;
+    if constexpr (OFFL) {
+        /* (the record was final long before the previous step ended — the ownship wave runs a batch ahead — so the
+         * caller read it ahead of that step's barrier; after a reset it is read here, behind the ownship wave's word) */
+        s0 = ob->s0;
+        if (!ob->have_s0) s0 = shp[0];
+    } else {
+        s0 = shp[0];                       /* same address for the whole lane group: one broadcast load */
+    }
     const float ox = s0.x, oy = s0.y;
     UAM_STAMP_AT(0);
 
@@ -2218,7 +2266,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
             P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN, KC>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            spawn_intruder<POS64, RNG, LEAN, KC, (LEAN && OFFL)>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true; sp_dirty = true;
         }
@@ -2834,7 +2882,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         const int env0 = blockIdx.x * E;
         const int rows = min(E, p.B - env0);
         int slot = 0, r3 = 0;
-        __syncthreads();
+        UAM_LDS_BARRIER();
 #if UAM_STAMP
         unsigned long long cw_work = 0, cw_wait = 0, cw_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -2848,8 +2896,8 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
 #if UAM_STAMP
             { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cw_work += t_ - cw_t; cw_t = t_; }
 #endif
-            __syncthreads();                                                   /* A: sweep k done */
-            if (two_bar) __syncthreads();                                      /* B */
+            UAM_LDS_BARRIER();                                                   /* A: sweep k done */
+            if (two_bar) UAM_LDS_BARRIER();                                      /* B */
 #if UAM_STAMP
             { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); cw_wait += t_ - cw_t; cw_t = t_; }
 #endif
@@ -2951,7 +2999,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
             int phase = 0;                           /* of the pass in progress for batch nb (0: none) */
             OwnBatch w;
             w.hd = 0.0; w.sp = 0.0; w.vx = 0.0; w.vy = 0.0; w.ox = 0.f; w.oy = 0.f;
-            __syncthreads();
+            UAM_LDS_BARRIER();
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int b = k >> JS, jr = k & (J - 1);
@@ -2963,14 +3011,21 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 if (phase == 0 && jr == min(1, J - 1) && nb == b + 1 && nb * J < K) phase = 1;
                 if (phase == 1) {
                     own_batch_p1a(pk, cl, bin, j, 0, jl, st, w);
+                    if (J >= UAM_OWN_SPLIT_J) {
+                        phase = 5;                   /* a long batch has a window to spare: the sincos gets its own */
+                    } else {
                     own_batch_p1b<KCO>(w);
                     phase = 2;
+                    }
                     if (J < 4) {
                         own_batch_p2a(j, 0, jl, st, w);
                         own_batch_p2b(pk, cl, on && j <= jl, le, j, st, w, rec, E, ring, slot_nb);
                         own_batch_p3(on, j, 0, jl, st, w);
                         phase = 4;
                     }
+                } else if (phase == 5) {
+                    own_batch_p1b<KCO>(w);
+                    phase = 2;
                 } else if (phase == 2) {
                     own_batch_p2a(j, 0, jl, st, w);
                     own_batch_p2b(pk, cl, on && j <= jl, le, j, st, w, rec, E, ring, slot_nb);
@@ -2986,7 +3041,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                     phase = 0;
                 }
                 UAM_OW_STAMP(ow_work);
-                __syncthreads();                                               /* A: sweep k done */
+                UAM_LDS_BARRIER();                                               /* A: sweep k done */
                 UAM_OW_STAMP(ow_wait);
                 const bool marked = on && ((const uint32_t*)(rec + 3 * E * slot_k + 3 * le))[3] == 0xFFFFFFFFu;
                 if (__ballot(marked)) {
@@ -2997,6 +3052,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                      * progress is finished first (from the state it started with), then redone for those envs. */
                     if (phase != 0) {
                         const int jl2 = min(J, K - nb * J) - 1;
+                        if (phase == 5) { own_batch_p1b<KCO>(w); phase = 2; }
                         if (phase == 2) {
                             own_batch_p2a(j, 0, jl2, st, w);
                             own_batch_p2b(pk, cl, on && j <= jl2, le, j, st, w, rec, E, ring, slot_nb);
@@ -3039,7 +3095,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 own_update<KCO>(pk, cl, own, cur, rec + 3 * lane);           /* step 0 */
                 if (K > 1) own_inputs<UAM_RNG_PHILOX>(pk, e, 1, own, cur, pka);
             }
-            __syncthreads();
+            UAM_LDS_BARRIER();
             int r3 = 0;
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
@@ -3051,7 +3107,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                     if (k + 2 < K) own_inputs<UAM_RNG_PHILOX>(pk, e, k + 2, own, nxt, pka);
                 }
                 UAM_OW_STAMP(ow_work);
-                __syncthreads();                                               /* A: sweep k done */
+                UAM_LDS_BARRIER();                                               /* A: sweep k done */
                 UAM_OW_STAMP(ow_wait);
                 if (owns && ((const uint32_t*)(rec_k + 3 * lane))[3] == 0xFFFFFFFFu) {
                     own_reload(p, e, own);                                     /* env was reset in step k */
@@ -3063,7 +3119,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 }
                 cur = nxt;
                 UAM_OW_STAMP(ow_work);
-                __syncthreads();                                               /* B: record k+1 final */
+                UAM_LDS_BARRIER();                                               /* B: record k+1 final */
                 UAM_OW_STAMP(ow_wait);
             }
             if (owns) own_store(p, e, own);
@@ -3098,7 +3154,9 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     *(float4*)(svy + SH4 + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
     OffBuf ob;
     ob.vel_prev = false;
-    __syncthreads();
+    ob.have_s0 = false;
+    ob.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    UAM_LDS_BARRIER();
     /* the sweeping wave is the step's critical path; the ownship and copy waves that share its SIMD fill the issue
      * slots it leaves (VALU issue is arbitrated by priority, then age) */
     __builtin_amdgcn_s_setprio(UAM_SWEEP_PRIO);
@@ -3117,9 +3175,14 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
 #else
         sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob);
 #endif
-        __syncthreads();                                                       /* A */
+        /* the next step's record, ahead of the barrier: tape mode with batches of at least four steps only (the
+         * ownship wave then finishes a batch's records at least one step before its first step; with a policy in the
+         * launch it finishes the next record between the two barriers), and not for a wave that reset an env in this step */
+        ob.have_s0 = !two_bar && J >= 4 && !__ballot(ob.had_reset);
+        if (ob.have_s0) ob.s0 = (rec + 3 * E * r3)[3 * (quad_ok ? g : 0)];
+        UAM_LDS_BARRIER();                                                       /* A */
         if (two_bar) {
-            __syncthreads();                                                   /* B */
+            UAM_LDS_BARRIER();                                                   /* B */
         } else if (__ballot(ob.had_reset)) {
             /* this wave reset an env: the ownship wave is redoing that env's records (rare: wait for its word) */
             __builtin_amdgcn_s_setprio(0);
