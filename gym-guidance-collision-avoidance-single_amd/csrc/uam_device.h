@@ -2052,6 +2052,8 @@ __device__ __forceinline__ void own_compute(const UamParams& p, UamColdRef c, co
  * sweepers are already in the next step. */
 struct OffBuf {
     float* px; float* py; float* vx; float* vy;   /* this step's half of the block's [T * 4] slot arrays (LDS) */
+    float* sp; float* hd;                          /* ... and of the held speeds / headings (instances that hold them) */
+    bool sp_prev;                                  /* some held speed of my quad changed in the previous step */
     uint2* out;                                    /* this step's half of the block's [E] (reward bits, done | info << 8) */
     bool vel_prev;                                 /* some velocity of my quad changed in the previous step */
     bool had_reset;                                /* out: my env was reset in this step (its later ownship records are being redone) */
@@ -2464,12 +2466,18 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     if constexpr (OFFL) {
         /* raw state of my quad, slot-linear ([thread][4]): two 16-byte LDS stores a step; velocities only when they
          * changed (respawn / reset) — in that step and in the next one, whose half of the double buffer is the other */
-        static_assert(!POS64 && !SH && (MODE & UAM_MODE_KNN) == 0, "the copy wave formats float32 [x, y, vx, vy] rows");
+        static_assert(!POS64 && (MODE & UAM_MODE_KNN) == 0, "the copy wave formats float32 rows of the intruders' fields");
         *(float4*)(ob->px + 4 * tid) = make_float4(q.x[0], q.x[1], q.x[2], q.x[3]);
         *(float4*)(ob->py + 4 * tid) = make_float4(q.y[0], q.y[1], q.y[2], q.y[3]);
         if (vel_dirty || ob->vel_prev) {
             *(float4*)(ob->vx + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
             *(float4*)(ob->vy + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
+            if constexpr (SH) *(float4*)(ob->hd + 4 * tid) = make_float4((float)q.hd[0], (float)q.hd[SH ? 1 : 0], (float)q.hd[SH ? 2 : 0], (float)q.hd[SH ? 3 : 0]);
+        }
+        if constexpr (SH) {
+            if (sp_dirty || ob->sp_prev)
+                *(float4*)(ob->sp + 4 * tid) = make_float4((float)q.sp[0], (float)q.sp[SH ? 1 : 0], (float)q.sp[SH ? 2 : 0], (float)q.sp[SH ? 3 : 0]);
+            ob->sp_prev = sp_dirty;
         }
         ob->vel_prev = vel_dirty;
     } else
@@ -2848,11 +2856,16 @@ template <int MODE, bool ROS, int LC, int OBSC, bool KCO>
 __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned char* lds_raw)
 {
     static_assert(LC >= 1 && LC <= 64 && (LC & (LC - 1)) == 0, "lane-group width: a power of two");
-    static_assert(OBSC == UAM_OBS_NORM4 || OBSC == UAM_OBS_RAW4, "four floats per intruder");
+    static_assert(OBSC == UAM_OBS_NORM4 || OBSC == UAM_OBS_RAW4 || OBSC == UAM_OBS_RAW6, "normalised or raw rows");
+    /* SH: the instance holds the intruders' speed and heading (RandIntruder dynamics, six floats per intruder in the row) */
+    constexpr bool SH = OBSC == UAM_OBS_RAW6 || (MODE & UAM_MODE_RI) != 0;
+    static_assert(!SH || OBSC == UAM_OBS_RAW6, "held speed / heading come with the six-wide raw row");
     constexpr int LS = LC == 1 ? 0 : LC == 2 ? 1 : LC == 4 ? 2 : LC == 8 ? 3 : LC == 16 ? 4 : LC == 32 ? 5 : 6;
-    constexpr int NC = 4 * LC, DC = 4 * NC + 8, CR = NC + 2;      /* intruders, row width, float4 chunks per row */
+    constexpr int OW = SH ? 6 : 4;                                  /* floats per intruder in the row */
+    constexpr int NC = 4 * LC, DC = OW * NC + 8, CR = DC / 4;      /* intruders, row width, float4 chunks per row */
+    constexpr int NARR = SH ? 6 : 4;                                /* slot arrays: px, py, vx, vy (, speed, heading) */
     UamParams p = p_in;
-    p.L = LC; p.lshift = LS; p.Q = LC; p.N = NC; p.Np = NC; p.D = DC; p.obs_w = 4; p.obs_vec = 1; p.obs_mode = OBSC;
+    p.L = LC; p.lshift = LS; p.Q = LC; p.N = NC; p.Np = NC; p.D = DC; p.obs_w = OW; p.obs_vec = 1; p.obs_mode = OBSC;
     p.knn = 0; p.track_ep = 0; p.shaped = 0; p.obs_direct = 0;
     const int K = p.many_K;
     const int T = (int)blockDim.x - 128;              /* sweeping threads; then the ownship wave, then the copy wave */
@@ -2870,10 +2883,11 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
      * the sweepers' next step behind the ownship wave's repair of a reset env's records — is a handshake here, paid only
      * by a sweeping wave that reset an env: it waits until `ack` (steps whose resets the ownship wave has dealt with)
      * has reached k + 1.  The in-launch policies keep barrier B (their ownship wave runs one step ahead only). */
-    uint32_t* const ack = (uint32_t*)(lds_raw + (size_t)ring * E * 48 + (size_t)E * 16 + (size_t)T * 128);
+    uint32_t* const ack = (uint32_t*)(lds_raw + (size_t)ring * E * 48 + (size_t)E * 16 + (size_t)T * 32 * NARR);
     const bool two_bar = p.many_policy >= 0;
     const int SH4 = T * 4;
     float* const spx = slots; float* const spy = slots + 2 * SH4; float* const svx = slots + 4 * SH4; float* const svy = slots + 6 * SH4;
+    float* const ssp = slots + 8 * SH4; float* const shd = slots + 10 * SH4;      /* (SH only; the row's field order) */
     const size_t slot_elems = (size_t)p.B * (size_t)DC;
 
     if (tid >= T + 64) {
@@ -2912,6 +2926,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                 if (p.info) p.info[orow] = (uint8_t)(o.y >> 8);
             }
             if (obs_k) {
+              if constexpr (OW == 4) {
                 /* Slot i of the block (thread i / 4's intruder i % 4) is intruder i % NC of row i / NC: consecutive lanes
                  * read consecutive LDS words and write consecutive 16-byte chunks of the rows (two tail chunks skipped
                  * per row).  All reads of the step are issued before the first store. */
@@ -2953,6 +2968,32 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
                     v.x = t2.x; v.y = t2.y; v.z = t2.z; v.w = t2.w;
                     __builtin_nontemporal_store(v, &dst[((lane + 64) >> 1) * CR + NC + (lane & 1)]);
                 }
+              } else {
+                /* six floats per intruder: a 16-byte chunk of a row straddles intruders, so every float finds its own
+                 * (intruder, field): field-major slot arrays in the row's field order, slots[field][half][row * NC + i] */
+                typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
+                uam_f32x4* const dst = (uam_f32x4*)(obs_k + (size_t)env0 * DC);
+                const float* const hs = slots + half * SH4;
+                const int chunks = rows * CR;
+#pragma unroll 2
+                for (int c = lane; c < chunks; c += 64) {
+                    const int row = c / CR, col4 = c - row * CR;
+                    uam_f32x4 v;
+                    if (col4 < (OW * NC) / 4) {
+                        float t4[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const int f = 4 * col4 + t, i = f / OW, fld = f - OW * i;
+                            t4[t] = hs[fld * 2 * SH4 + row * NC + i];
+                        }
+                        v.x = t4[0]; v.y = t4[1]; v.z = t4[2]; v.w = t4[3];
+                    } else {
+                        const float4 tl = rec_k[3 * row + 1 + (col4 - (OW * NC) / 4)];
+                        v.x = tl.x; v.y = tl.y; v.z = tl.z; v.w = tl.w;
+                    }
+                    __builtin_nontemporal_store(v, &dst[c]);
+                }
+              }
             }
         }
 #if UAM_STAMP
@@ -3139,12 +3180,12 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     const int env = blockIdx.x * E + g;
     const bool quad_ok = env < p.B && g < E;
     const size_t base = (size_t)env * NC + 4u * gl;
-    Quad<false, false> q;
+    Quad<false, SH> q;
     bool vel_dirty = false;
 #if UAM_STAMP
     unsigned long long stamp_acc[UAM_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    quad_load<false, false>(p, base, quad_ok, q);
+    quad_load<false, SH>(p, base, quad_ok, q);
     int32_t ncf = (quad_ok && gl == 0) ? p.s.no_conflict[env] : 0;
     __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0): see sweep_many_body */
     /* both halves of the velocity slots start out current */
@@ -3152,8 +3193,15 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     *(float4*)(svy + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
     *(float4*)(svx + SH4 + 4 * tid) = make_float4(q.vx[0], q.vx[1], q.vx[2], q.vx[3]);
     *(float4*)(svy + SH4 + 4 * tid) = make_float4(q.vy[0], q.vy[1], q.vy[2], q.vy[3]);
+    if constexpr (SH) {
+        const float4 s4 = make_float4((float)q.sp[0], (float)q.sp[SH ? 1 : 0], (float)q.sp[SH ? 2 : 0], (float)q.sp[SH ? 3 : 0]);
+        const float4 h4 = make_float4((float)q.hd[0], (float)q.hd[SH ? 1 : 0], (float)q.hd[SH ? 2 : 0], (float)q.hd[SH ? 3 : 0]);
+        *(float4*)(ssp + 4 * tid) = s4; *(float4*)(ssp + SH4 + 4 * tid) = s4;
+        *(float4*)(shd + 4 * tid) = h4; *(float4*)(shd + SH4 + 4 * tid) = h4;
+    }
     OffBuf ob;
     ob.vel_prev = false;
+    ob.sp_prev = false;
     ob.have_s0 = false;
     ob.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
     UAM_LDS_BARRIER();
@@ -3168,12 +3216,13 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         const int half = k & 1;
         ob.px = spx + half * SH4; ob.py = spy + half * SH4; ob.vx = svx + half * SH4; ob.vy = svy + half * SH4;
         ob.out = outb + half * E;
+        ob.sp = ssp + half * SH4; ob.hd = shd + half * SH4;
         ob.had_reset = false;
 #if UAM_STAMP
-        sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob, stamp_acc);
+        sweep_step<false, UAM_RNG_PHILOX, MODE, SH, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob, stamp_acc);
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
 #else
-        sweep_step<false, UAM_RNG_PHILOX, MODE, false, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob);
+        sweep_step<false, UAM_RNG_PHILOX, MODE, SH, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob);
 #endif
         /* the next step's record, ahead of the barrier: tape mode with batches of at least four steps only (the
          * ownship wave then finishes a batch's records at least one step before its first step; with a policy in the
@@ -3201,8 +3250,8 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     }
 #endif
     if (quad_ok) {
-        quad_store_pos<false, false>(p, base, q);
-        if (vel_dirty) quad_store_vel<false, false>(p, base, q);
+        quad_store_pos<false, SH>(p, base, q);
+        if (vel_dirty) quad_store_vel<false, SH>(p, base, q);
         p.s.qf[base >> 2] = (uint8_t)q.flags;
     }
     if (quad_ok && gl == 0) p.s.no_conflict[env] = ncf;
@@ -3216,7 +3265,6 @@ __global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     sweep_many3_body<MODE, ROS, LC, OBSC, KCO>(p, lds_raw);
 }
-
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
 __global__ void UAM_MANY_BOUNDS uam_sweep_many_kernel(const UamParams p)
 {

@@ -697,13 +697,21 @@ static UamSweepFn many3_fn_l(const uam_env* e, int kco)
 }
 static UamSweepFn many3_fn(const uam_env* e, int kco)
 {
-    if (!many_instance_exists(e) || e->cfg.dynamics == UAM_DYN_RANDINTRUDER || e->cfg.shaped_reward || e->hold_sh ||
-        e->cfg.random_own_start || e->cfg.track_episodes)
-        return nullptr;
-    if (e->cfg.obs_mode != UAM_OBS_NORM4 && e->cfg.obs_mode != UAM_OBS_RAW4) return nullptr;
+    if (!many_instance_exists(e) || e->cfg.shaped_reward || e->cfg.random_own_start || e->cfg.track_episodes) return nullptr;
     if (e->cfg.num_intruders != 4 * e->L) return nullptr;          /* full quads, and Q = L */
     if (e->Tm3 > 128 || e->Em3 < 1) return nullptr;                /* the copy wave holds T / 16 <= 8 slots per lane */
     if (kco < 0) kco = e->many3_kco;
+    if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) {
+        /* RandIntruder: held speed / heading, six-wide raw rows (the variant's only observation) */
+        if (e->cfg.obs_mode != UAM_OBS_RAW6) return nullptr;
+        switch (e->L) {
+        case 8: return uam_sweep_many3_kernel<UAM_MODE_RI, false, 8, UAM_OBS_RAW6, true>;
+        case 16: return uam_sweep_many3_kernel<UAM_MODE_RI, false, 16, UAM_OBS_RAW6, true>;
+        default: return nullptr;
+        }
+    }
+    if (e->hold_sh) return nullptr;
+    if (e->cfg.obs_mode != UAM_OBS_NORM4 && e->cfg.obs_mode != UAM_OBS_RAW4) return nullptr;
     switch (e->L) {
     case 2: return many3_fn_l<2>(e, kco);
     case 4: return many3_fn_l<4>(e, kco);
@@ -717,7 +725,7 @@ static UamSweepFn many3_fn(const uam_env* e, int kco)
 static inline size_t lds_many3(const uam_env* e)
 {
     const int J = 64 / e->Em3 < 16 ? (64 / e->Em3 > 0 ? 64 / e->Em3 : 1) : 16;
-    return (size_t)(2 * J + 1) * e->Em3 * 48 + (size_t)e->Em3 * 16 + (size_t)e->Tm3 * 128 + 16;      /* + the reset handshake word */
+    return (size_t)(2 * J + 1) * e->Em3 * 48 + (size_t)e->Em3 * 16 + (size_t)e->Tm3 * 32 * (e->hold_sh ? 6 : 4) + 16;      /* + the reset handshake word */
 }
 static inline int grid_many3(const uam_env* e) { return (e->cfg.num_envs + e->Em3 - 1) / e->Em3; }
 

@@ -34,6 +34,8 @@ def uamenv():
     ("continuous", 16384, 32, 11, 2, True),    # two sweeping waves per block, 4 steps per ownship pass
     ("discrete9", 65536, 8, 5, 1, True),       # 64 envs per block: one step per ownship pass
     ("continuous2", 1000, 64, 19, 19, True),   # partial last block, K not a multiple of the pass length
+    ("randintruder", 8192, 64, 9, 2, True),    # BASELINE config 5's shape: held speed / heading, six-wide rows, two sweeping waves
+    ("randintruder", 4096, 32, 12, 3, True),   # ... with 8 lanes per env
 ])
 def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     """Slot k % R of the rollout's obs buffer must hold exactly what uam_step would have returned at step k, and
@@ -44,7 +46,7 @@ def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     a.reset(); b.reset()
     dev = a.device
     assert (a.steps_per_launch(K) == K) == looped, "unexpected launch form"
-    if variant in ("mcts", "continuous2") or (variant, B) in (("continuous", 16384), ("discrete9", 65536), ("continuous", 8192), ("discrete9", 4096)):
+    if variant in ("mcts", "continuous2", "randintruder") and B != 65536 or (variant, B) in (("continuous", 16384), ("discrete9", 65536), ("continuous", 8192), ("discrete9", 4096)):
         want_kernel = "uam_sweep_many4_kernel" if (variant, B, N) == ("discrete9", 65536, 32) else "uam_sweep_many3_kernel"
         assert a.rollout_kernel(K) == want_kernel, a.rollout_kernel(K)
     for rep in range(2):
