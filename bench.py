@@ -104,7 +104,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(B, N, nthreads):
+def cpu_baseline(B, N, nthreads, scale=1.0):
     """Oracle (kind 'port') on a bounded sample of the same workload: all host threads, then one thread."""
     import numpy as np
     from oracle import oracle
@@ -129,15 +129,15 @@ def cpu_baseline(B, N, nthreads):
 
     aff = len(os.sched_getaffinity(0))
     quota = cpu_quota()
-    cores = max(1, min(aff, quota)) if quota else aff      # the CPUs this process can actually keep busy
+    cores = max(1, min(aff, int(quota + 0.5))) if quota else aff      # the CPUs this process can actually keep busy
     # thread counts tried: the CPUs the cgroup grants, the pool's per-GPU share (16) and every CPU of the affinity mask;
     # `value` is the best of them — on a box whose CPU share is enforced by throttling, one thread per visible CPU is
     # far slower than one per granted CPU (measured: 256 threads 0.48 M, 16 threads 9.8 M env-steps/s)
     tried = {}
-    for nt, secs in sorted({cores: 5.0, nthreads: 5.0, aff: 3.0}.items()):
-        tried[nt] = rate(nt, secs)
+    for nt, secs in sorted({int(cores): 5.0, int(nthreads): 5.0, int(aff): 3.0}.items()):
+        tried[nt] = rate(int(nt), secs * scale)
     best = max(tried, key=lambda k: tried[k][0])
-    v_one, s_one = rate(1, 4.0)
+    v_one, s_one = rate(1, 4.0 * scale)
     out = {"value": tried[best][0], "unit": "env-steps/s", "cores": best, "kind": "port",
            "sample": "oracle/uam_oracle.c (OpenMP over envs), %d envs x %d intruders, random actions, float64 obs written; "
                      "threads tried: %s (steps run: %s) — `value` is the best; affinity mask %d CPUs, cgroup quota %s; "

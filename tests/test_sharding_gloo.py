@@ -232,3 +232,16 @@ def test_bench_self_launch_spawns_ranks_before_any_gpu_call(monkeypatch):
     src = open(os.path.join(ROOT, "bench.py")).read()
     head = src[:src.index("def parse_args")]
     assert "import torch" not in head and "import uamenv" not in head   # nothing GPU-capable at module import
+
+
+def test_bench_cpu_baseline_with_a_fractional_cgroup_quota(monkeypatch):
+    """bench.py's cpu_baseline on a box whose cgroup grants a fractional number of CPUs (cpu.max "1650000 100000"): the
+    thread counts it tries must be integers (a float reached the oracle's ctypes binding once and the driver's line
+    carried `cpu_baseline.value: null`), `value` is the best of them and `cores` names it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "cpu_quota", lambda: 2.6)
+    out = bench.cpu_baseline(256, 4, 2, scale=0.02)
+    assert out["value"] and out["value"] > 0 and out["kind"] == "port" and out["single_thread"] > 0
+    assert isinstance(out["cores"], int) and str(out["cores"]) in out["by_threads"]
+    assert out["value"] == max(out["by_threads"].values()) and out["cgroup_cpu_quota"] == 2.6
