@@ -1482,7 +1482,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
     const int lane = threadIdx.x & 63;
     const UAM_LDS_U32 big = (UAM_LDS_U32)lds;
     const UAM_LDS_F64W slots = (UAM_LDS_F64W)(lds + UAM_MT_BIG) + 20 * gl;
-    const int Q = p.Q;
+    const int Q = max(p.Q, 1);       /* (an env without intruders — the packaged copy's default — still draws its goal: lane 0's) */
     unsigned long long pend = __ballot(need && gl == 0);
     while (pend) {                                   /* wave-uniform: one resetting env at a time */
         const int src = __ffsll((long long)pend) - 1;

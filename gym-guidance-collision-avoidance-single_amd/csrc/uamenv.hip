@@ -139,8 +139,9 @@ static int validate(const uam_config* c)
     if (c->struct_size != sizeof(uam_config))
         return fail(UAM_EINVAL, "uam_config.struct_size %u != %zu (ABI mismatch)", c->struct_size, sizeof(uam_config));
     if (c->num_envs < 1) return fail(UAM_EINVAL, "num_envs must be >= 1 (got %d)", c->num_envs);
-    if (c->num_intruders < 1 || c->num_intruders > 256)
-        return fail(UAM_EINVAL, "num_intruders must be in 1..256 (got %d)", c->num_intruders);
+    /* 0: a map with the ownship and a goal only — the packaged copy's own default (envs/config.py:8) */
+    if (c->num_intruders < 0 || c->num_intruders > 256)
+        return fail(UAM_EINVAL, "num_intruders must be in 0..256 (got %d)", c->num_intruders);
     if ((int64_t)c->num_envs * ((c->num_intruders + 3) & ~3) > (int64_t)1 << 31)
         return fail(UAM_EINVAL, "num_envs*num_intruders too large for one handle");
     if (c->obs_mode < 0 || c->obs_mode > UAM_OBS_KNN5) return fail(UAM_EINVAL, "bad obs_mode %d", c->obs_mode);

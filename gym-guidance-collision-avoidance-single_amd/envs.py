@@ -59,7 +59,8 @@ class Config:
 
 class PackagedConfig(Config):
     """The constants the packaged (deprecated) copy runs with: gym_guidance_collision_avoidance_single/envs/config.py
-    (heading_sigma 2 degrees, intruder_size 0 — pass num_intruders) and the literals of its
+    (heading_sigma 2 degrees, intruder_size 0: a map with the ownship and a goal only, which is what
+    `PackagedSingleAircraft2Env()` then runs — pass num_intruders for more) and the literals of its
     SingleAircraft2Env._terminal_reward (:155-176): NMAC -5, conflict -1, out of map -100 and terminal, goal +1."""
     intruder_size = 0
     heading_sigma = math.radians(2)
@@ -693,12 +694,6 @@ class PackagedSingleAircraft2Env(SingleAircraftEnv):
 
     def __init__(self, num_intruders=None, seed=None, device=None, rng="mt19937", precision="exact", config=PackagedConfig,
                  **overrides):
-        n = config.intruder_size if num_intruders is None else num_intruders
-        if int(n) < 1:
-            # the packaged config ships intruder_size = 0 (envs/config.py:8): a map with the ownship and a goal only.
-            # The batched kernels own one quad of intruders per lane and are not built for an empty sweep.
-            raise ValueError("PackagedSingleAircraft2Env: the packaged default intruder_size = 0 is not supported by "
-                             "the HIP path; pass num_intruders >= 1 (INTEGRATION.md, 'Packaged copy')")
         super().__init__(num_intruders, seed, device, rng, precision, config, **overrides)
 
     def _encode_action(self, action):

@@ -696,7 +696,7 @@ void orc_nearest(const orc_batch* b, double* out, uint8_t* is_f64_out)
 /* ------------------------------------------------------------------ batch API */
 orc_batch* orc_create(const uam_config* cfg, int math_impl, int shared_stream)
 {
-    if (!cfg || cfg->struct_size != sizeof(uam_config) || cfg->num_envs < 1 || cfg->num_intruders < 1) return NULL;
+    if (!cfg || cfg->struct_size != sizeof(uam_config) || cfg->num_envs < 1 || cfg->num_intruders < 0) return NULL;      /* 0: the packaged copy's default, ownship and goal only */
     orc_batch* b = (orc_batch*)calloc(1, sizeof(*b));
     b->cfg = *cfg;
     if (b->cfg.rng_mode == UAM_RNG_MT19937_SHARED) { b->cfg.rng_mode = UAM_RNG_MT19937; shared_stream = 1; }   /* the product's spelling */

@@ -388,7 +388,7 @@ def g8_continuous(Config, m_env2):
                                         dynamics=0), data)
 
 
-def g8b_packaged_continuous2(ref):
+def g8b_packaged_continuous2(ref, N=8, seed=17, name="g8b_packaged_continuous2_n8_seed17", T=900):
     """G8 'second mode': the PACKAGED copy gym_guidance_collision_avoidance_single/envs/SingleAircraft2Env.py — action
     (a[0], a[1]) un-offset with a live speed command (:281-285), its own reward literals (NMAC -5, conflict -1,
     goal +1) and the out-of-map termination 'w' (-100, :169-170), heading_sigma 2 degrees (envs/config.py).  The module
@@ -401,9 +401,8 @@ def g8b_packaged_continuous2(ref):
     sys.modules["_gcas_packaged_envs"] = pkg
     m = importlib.import_module("_gcas_packaged_envs.SingleAircraft2Env")
     PConfig = importlib.import_module("_gcas_packaged_envs.config").Config
-    N = 8
-    PConfig.intruder_size = N
-    np.random.seed(17)
+    PConfig.intruder_size = N      # (N = 0 is the packaged config's own default: a map with the ownship and a goal only)
+    np.random.seed(seed)
     env = m.SingleAircraft2Env()
     obs0 = env.reset()
     st0 = snapshot(env)
@@ -429,12 +428,12 @@ def g8b_packaged_continuous2(ref):
         a1 = np.clip(arng.uniform(-1, 1), -1, 1)
         return np.array([np.float32(a0), np.float32(a1)], dtype=np.float64)   # float32-valued, like the C-ABI carries
 
-    data = run_episode_stream(env, act, 900, 20)
+    data = run_episode_stream(env, act, T, 20)
     data["obs0"] = np.asarray(obs0)
     add_prefixed(data, "st0_", st0)
     data["actions"] = np.asarray(data["actions"], dtype=np.float32)
-    save("g8b_packaged_continuous2_n8_seed17",
-         dict(seed=17, N=N, variant="packaged SingleAircraft2Env", obs_mode=0, action_mode=4, dynamics=0,
+    save(name,
+         dict(seed=seed, N=N, variant="packaged SingleAircraft2Env", obs_mode=0, action_mode=4, dynamics=0,
               heading_sigma=PConfig.heading_sigma, speed_sigma=PConfig.speed_sigma, nmac_penalty=-5.0,
               conflict_penalty=-1.0, wall_penalty=-100.0, goal_reward=1.0, wall_terminates=1), data)
 
@@ -544,6 +543,7 @@ def main():
                 "conflict masks goal until the intruder leaves")
     g8_continuous(Config, m_env2)
     g8b_packaged_continuous2(args.ref)
+    g8b_packaged_continuous2(args.ref, N=0, seed=23, name="g8c_packaged_default_n0_seed23", T=1500)
     g9_randintruder(Config, m_ri, 8, 13, 1500)
     g9_randintruder(Config, m_ri, 64, 14, 500)
     g9b_mctsenv(Config, m_mcts)
@@ -552,6 +552,11 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g8c":       # only the packaged default (no intruders) fixture
+        sys.dont_write_bytecode = True
+        install_gym_stub()
+        g8b_packaged_continuous2("/root/reference", N=0, seed=23, name="g8c_packaged_default_n0_seed23", T=1500)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "g8b":       # only the packaged-copy fixture
         sys.dont_write_bytecode = True
         install_gym_stub()

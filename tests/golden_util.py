@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAJECTORY_FIXTURES = [
     "g1_discrete9_n4_seed0", "g2_goalseek_n8_seed3", "g2_goalseek_n32_seed1", "g2_goalseek_n80_seed4",
     "g3_nmac_early_exit", "g4_respawn_in_conflict", "g5_conflict_masks_goal",
-    "g8_continuous_n8_seed7", "g8b_packaged_continuous2_n8_seed17", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
+    "g8_continuous_n8_seed7", "g8b_packaged_continuous2_n8_seed17", "g8c_packaged_default_n0_seed23", "g9_randintruder_n8_seed13", "g9_randintruder_n64_seed14",
     "g9b_mctsenv_n8_seed11", "g6b_randomenv_n8_seed31",
 ]
 

@@ -70,7 +70,7 @@ def test_no_gpu_is_a_loud_failure(capi):
 
 def test_bad_config_is_rejected_before_touching_a_device(capi):
     h = C.c_void_p()
-    for field, val in [("num_envs", 0), ("num_intruders", 0), ("num_intruders", 257), ("obs_mode", 9),
+    for field, val in [("num_envs", 0), ("num_intruders", -1), ("num_intruders", 257), ("obs_mode", 9),
                        ("rng_mode", 5), ("struct_size", 8)]:
         cfg = capi.default_config(4, 8)
         setattr(cfg, field, val)

@@ -266,6 +266,44 @@ def test_packaged_2env_gym_class_is_a_drop_in(uamenv):
     env.close()
 
 
+def test_packaged_default_without_intruders(uamenv, oracle):
+    """The packaged copy's own default, Config.intruder_size = 0 (envs/config.py:8): a map with the ownship and a goal
+    only.  `PackagedSingleAircraft2Env()` — no arguments, as the reference's callers construct it — replays fixture g8c
+    (recorded from the reference with N = 0: goals, out-of-map terminations, 8-wide observation) from seed(23); and the
+    batched env without intruders matches the oracle in lockstep in both RNG modes, through resets, single steps and the
+    looped kernel."""
+    import torch
+    fx = gu.load("g8c_packaged_default_n0_seed23")
+    env = uamenv.PackagedSingleAircraft2Env()
+    assert env.intruder_size == 0 and env.observation_space.shape == (8,)
+    env.seed(23)
+    assert np.abs(env.reset() - fx["obs0"]).max() <= 1e-5
+    reset_steps = {int(t): i for i, t in enumerate(fx["reset_steps"])}
+    seen = set()
+    for t in range(len(fx["done"])):
+        ob, r, d, info = env.step(fx["actions"][t])
+        assert info == ["", "c", "g", "n", "w"][int(fx["info"][t])], t
+        assert ob.shape == (8,) and d == bool(fx["done"][t]) and abs(r - fx["reward"][t]) <= 1e-5 and np.abs(ob - fx["obs"][t]).max() <= 1e-5, t
+        seen.add(info)
+        if d:
+            assert np.abs(env.reset() - fx["reset_obs"][reset_steps[t]]).max() <= 1e-5
+    assert {"g", "w"} <= seen
+    env.close()
+    for rng, precision in (("philox", "f32"), ("mt19937", "exact")):
+        pu.run_lockstep(uamenv, oracle, 300, 0, 120, policy="goal", rng=rng, precision=precision, variant="continuous2",
+                        wall_terminates=1, check_state_every=20)
+    a = uamenv.BatchedSingleAircraftEnv(2000, 0, variant="discrete9", seed=4)
+    b = uamenv.BatchedSingleAircraftEnv(2000, 0, variant="discrete9", seed=4)
+    a.reset(); b.reset()
+    tape = torch.stack([a.policy_actions("goal", seed=k) for k in range(30)]).contiguous()
+    _, rew, done, info = a.step_many(tape)
+    for k in range(30):
+        o, r, d, i = b.step(tape[k])
+        assert torch.equal(rew[k], r) and torch.equal(done[k], d.view(torch.uint8)), k
+    assert torch.equal(a.observe(), b.observe())
+    a.close(); b.close()
+
+
 def test_reset_mask_state_roundtrip_and_step_many(uamenv, oracle):
     import torch
     B, N = 64, 8
