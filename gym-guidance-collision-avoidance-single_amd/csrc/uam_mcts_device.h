@@ -33,6 +33,9 @@
 #define UAM_MCTS_SMALL_NODES 128        /* tree capacity of the small instances (simulations <= 126) */
 #define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
 #define UAM_MCTS_WAVES_PER_BLOCK 2
+#ifndef UAM_MCTS_PHILOX_WIDE
+#define UAM_MCTS_PHILOX_WIDE 1          /* 64-bit products (v_mad_u64_u32): half the quarter-rate multiplies of a block */
+#endif
 #ifndef UAM_MCTS_WAVES_PER_EU
 #define UAM_MCTS_BOUNDS __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK)
 #else
@@ -89,7 +92,7 @@ __device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgc
 
 __device__ __forceinline__ void mcts_philox(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx, uint32_t* w)
 {
-    uam_philox(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, r.k0, r.k1, w);
+    uam_philox_t<UAM_MCTS_PHILOX_WIDE != 0>(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, r.k0, r.k1, w);
 }
 
 __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx,
@@ -105,132 +108,242 @@ __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepai
     z1 = rr * sn;
 }
 
+/* ---- ownship noise, drawn ahead.  The Box-Muller pairs of the ownship only depend on (root, simulation, move,
+ * frame pair), never on a state, so they are drawn for SEVERAL simulations in one lane-parallel pass (lane = one
+ * frame pair of one move of one simulation: 60 of 64 lanes busy at depth 3 x 5 frame pairs x 4 simulations) into a
+ * 1 KB LDS table per root instead of once per move with (F + 1) / 2 lanes busy: the Philox + log + sqrt + sincos of
+ * a pass (~250 wave instructions) are paid once per ~8 moves.  Same counters, same values as a draw in place.
+ * Layout: doubles [2 e], [2 e + 1] = the pair of entry e = ((sim - sim0) * nmv + (mv - mv0)) * FP + frame pair;
+ * with speed noise (speed_sigma != 0) the table is split: heading pairs in [0, 64), speed pairs in [64, 128). */
+#define UAM_MCTS_NZ_DOUBLES 128
+struct MctsNoise {
+    double* tab;
+    int sim0, nsim, mv0, nmv;            /* what the table holds (wave-uniform) */
+    bool per_move;                        /* depth x frame pairs exceed the table: refill before every move */
+};
+
+__device__ __forceinline__ int mcts_noise_cap(const UamMctsParams& p) { return p.speed_sigma != 0.0 ? 32 : 64; }
+
+__device__ inline void mcts_fill_noise(const UamMctsParams& p, const MctsRng& base, MctsNoise& nz, const int sim0,
+                                       const int nsim, const int mv0, const int nmv, const int lane)
+{
+    const int FP = (p.frames + 1) >> 1, per = nmv * FP, tot = nsim * per;
+    const bool spd = p.speed_sigma != 0.0;
+    for (int e = lane; e < tot; e += 64) {
+        const int si = e / per, r = e - si * per, m = r / FP, fp = r - m * FP;
+        MctsRng g = base;
+        g.sim = (uint32_t)(sim0 + si); g.mv = (uint32_t)(mv0 + m);
+        double z0, z1;
+        mcts_normals(g, (uint32_t)fp, UAM_MPH_OWN_H, 0, z0, z1);
+        nz.tab[2 * e] = z0; nz.tab[2 * e + 1] = z1;
+        if (spd) {
+            mcts_normals(g, (uint32_t)fp, UAM_MPH_OWN_S, 0, z0, z1);
+            nz.tab[64 + 2 * e] = z0; nz.tab[64 + 2 * e + 1] = z1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    nz.sim0 = sim0; nz.nsim = nsim; nz.mv0 = mv0; nz.nmv = nmv;
+}
+
+/* the heading-change word of (frame f, intruder i): word f & 3 of the frame quad's block */
+__device__ __forceinline__ uint32_t mcts_hc_word(const MctsRng& rng, const int f, const int i)
+{
+    uint32_t w4[4];
+    mcts_philox(rng, (uint32_t)f >> 2, UAM_MPH_HEADCHG, (uint32_t)i, w4);
+    return w4[f & 3];
+}
+
 /* SingleAircraftState.move, nodes_single_randintru.py:39-114.  `sp` = per-slot intruder speed (constant
  * over the tree).  Returns flag bits: 1 hit_wall, 2 conflict, 4 reach_goal.
  *
- * The ownship's trajectory over the move's frames does not depend on the intruders, so it is computed
- * up front with the frames spread over lanes: the Box-Muller pairs (lane j = frame pair j) and the
- * sincos of every frame's heading (lane f = frame f) are evaluated ONCE in parallel instead of once per
- * frame wave-uniformly.  The recurrences themselves (speed clamp, heading, position sums) run in the
- * reference's order, sequentially, so every rounding is the reference's.  Needs frames <= 64. */
-/* Heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on positions, so
- * all of a move's changes are drawn in a PRE-PASS; every changed heading goes into a wave-level LDS queue
- * (slot = running ballot rank, frame-major), the queue's sincos are evaluated DENSELY (lane j takes entry j,
- * j+64, ...: ~N entries per move instead of F sparse evaluations with ~10 % of the lanes active), and the frame
- * loop picks its (heading, cos, sin) up by recomputing the same ballot rank.  Entries beyond the queue's
- * capacity (never at the shipped 10 % rate, but possible) are evaluated in place as before. */
+ * The ownship's trajectory over the move's frames does not depend on the intruders, so it is computed up front with
+ * the frames spread over lanes: LANE f + 1 HOLDS FRAME f, lane 0 the state before the move.  The sincos of every
+ * frame's heading is evaluated once, in parallel.  The recurrences (heading: two additions a frame; speed: addition,
+ * clamp, addition; position: one addition per axis) are WALKED through the lanes: F times, every lane takes its left
+ * neighbour's value (DPP wave_shr:1, no LDS, no scalar round trip) and applies its own frame's update — after step
+ * t lanes 0..t+1 are final and stay so, because they recompute the same value from final inputs.  Lane 0's update is
+ * the identity (increment 0, clamp to +-inf, noise 0), so no lane needs a select.  Each frame's value is produced
+ * by the reference's operations in the reference's order on the reference's inputs: every rounding is the
+ * reference's.  Four VALU instructions per double and frame instead of readlane broadcasts, multiplies and selects
+ * (~9).  Needs frames <= 63. */
+/* Heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on positions, so all of
+ * a move's changes are settled in a PRE-PASS in three steps.  (1) Per frame, one compare per lane marks the changes
+ * (bit f of chg), the change's word goes into a wave-level LDS queue (slot = running ballot rank, frame-major) and
+ * the ballot and its running base are noted per frame — no arithmetic under the divergent branch.  (2) Every lane
+ * walks ITS OWN changes in frame order (a loop over the set bits of chg: as many trips as the busiest lane has
+ * changes, ~3-4 of 10 frames at the shipped 10 %, instead of one divergent body per frame), accumulates its heading
+ * and leaves it in the queue.  (3) The queue's sincos are evaluated DENSELY (lane j takes entry j, j + 64, ...: ~N
+ * entries per move instead of F sparse evaluations with ~10 % of the lanes active).  The frame loop then picks its
+ * (heading, cos, sin) up by recomputing the same ballot rank.  Entries beyond the queue's capacity (never at the
+ * shipped rate, but possible) are evaluated in place. */
 #define UAM_MCTS_QCAP(K) (128 * (K))
+#define UAM_DPP_WAVE_SHR1 0x138
 
 template <int K, int MODEL>
 __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
                                      const double gx, const double gy, const int a0, const int a1, MctsState<K>& s,
-                                     double* qbuf)
+                                     double* qbuf, MctsNoise& nz)
 {
     constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
     constexpr int QCAP = UAM_MCTS_QCAP(K);
     double* const qh = qbuf;              /* heading after the change */
     double* const qc = qbuf + QCAP;       /* its cosine */
     double* const qs = qbuf + 2 * QCAP;   /* its sine */
-    (void)qh; (void)qc; (void)qs;
+    /* scratch of the pre-pass, dead before the dense sincos writes qc / qs: per (frame, slot) ballot and base */
+    unsigned long long* const tab_m = (unsigned long long*)qc;     /* [F * K] <= 63 K * 8 B */
+    int* const tab_b = (int*)(tab_m + 64 * K);                     /* [F * K]: 512 K + 256 K <= 1024 K B */
+    uint32_t* const qw = (uint32_t*)qs;                            /* [QCAP] the changes' words */
+    (void)qh; (void)qc; (void)qs; (void)tab_m; (void)tab_b; (void)qw;
     const int F = p.frames;
     const double d_heading = (double)(a0 - 1) * p.d_heading;
     const double accel = (double)(a1 - 1) * p.d_speed;
-    /* ---- ownship noise: one Box-Muller pair per frame pair, :75,:78 */
-    double zhp0 = 0.0, zhp1 = 0.0, zsp0 = 0.0, zsp1 = 0.0;
-    if (lane < ((F + 1) >> 1)) {
-        mcts_normals(rng, (uint32_t)lane, UAM_MPH_OWN_H, 0, zhp0, zhp1);
-        if (p.speed_sigma != 0.0) mcts_normals(rng, (uint32_t)lane, UAM_MPH_OWN_S, 0, zsp0, zsp1);
+    /* ---- ownship noise of this move's frames from the table: lane f + 1 reads frame f's normal, :75,:78 */
+    if (nz.per_move) mcts_fill_noise(p, rng, nz, (int)rng.sim, 1, (int)rng.mv, 1, lane);
+    const bool fr = lane >= 1 && lane <= F;
+    double zh = 0.0, zs = 0.0;
+    {
+        const int e0 = (((int)rng.sim - nz.sim0) * nz.nmv + ((int)rng.mv - nz.mv0)) * ((F + 1) >> 1);
+        if (fr) {
+            zh = nz.tab[2 * e0 + lane - 1];
+            if (p.speed_sigma != 0.0) zs = nz.tab[64 + 2 * e0 + lane - 1];
+        }
     }
-    const int src = lane >> 1;
-    const double zha = __shfl(zhp0, src), zhb = __shfl(zhp1, src), zsa = __shfl(zsp0, src), zsb = __shfl(zsp1, src);
-    const double zh = (lane & 1) ? zhb : zha, zs = (lane & 1) ? zsb : zsa;      /* lane f holds frame f's noise */
-    double my_sp = 0.0, my_hd = 0.0, my_vx = 0.0, my_vy = 0.0, my_ox = 0.0, my_oy = 0.0;
+    const double hnoise = fr ? 0.0 + p.heading_sigma * zh : 0.0;
+    const double snoise = fr ? 0.0 + p.speed_sigma * zs : 0.0;
+    const double dh_l = lane == 0 ? 0.0 : d_heading;
+    const double lo_l = lane == 0 ? -__builtin_inf() : p.min_speed, hi_l = lane == 0 ? __builtin_inf() : p.max_speed;
+    double my_sp, my_hd, my_vx, my_vy, my_ox, my_oy;
     if constexpr (!M4) {
         /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
+        const double ac_l = lane == 0 ? 0.0 : accel;
         double spd = s.osp, hdg = s.ohd;
-        for (int f = 0; f < F; f++) {
-            const double zsf = lane_bcast(zs, f), zhf = lane_bcast(zh, f);
-            spd += accel;
-            spd = fmax(p.min_speed, fmin(spd, p.max_speed));
-            spd += 0.0 + p.speed_sigma * zsf;
-            hdg += d_heading;
-            hdg += 0.0 + p.heading_sigma * zhf;
-            if (lane == f) { my_sp = spd; my_hd = hdg; }
+#pragma unroll 1
+        for (int t = 0; t < F; t++) {
+            double v = dpp_mov<UAM_DPP_WAVE_SHR1>(spd), h = dpp_mov<UAM_DPP_WAVE_SHR1>(hdg);
+            v += ac_l;
+            v = fmax(lo_l, fmin(v, hi_l));
+            v += snoise;
+            h += dh_l;
+            h += hnoise;
+            spd = v; hdg = h;
         }
+        my_sp = spd; my_hd = hdg;
         /* ---- every frame's velocity at once, :81-82 */
         double sn, cs;
         uam_sincos_k(my_hd, &sn, &cs);
         my_vx = my_sp * cs; my_vy = my_sp * sn;
-        /* ---- positions in frame order, :83-86 */
-        double ox = s.ox, oy = s.oy;
-        for (int f = 0; f < F; f++) {
-            ox += lane_bcast(my_vx, f);
-            oy += lane_bcast(my_vy, f);
-            if (lane == f) { my_ox = ox; my_oy = oy; }
-        }
     } else {
         /* nodes_single.py:59-71: the heading recurrence is independent of the speed, so every frame's heading
-         * and its sincos come first (lane f = frame f); the speed is then re-derived each frame from the
-         * previous frame's vy (state[-5], :60 — `accel` is dead), which chains through sin(heading) */
+         * and its sincos come first; the speed is then re-derived each frame from the previous frame's vy
+         * (state[-5], :60 — `accel` is dead), which chains through sin(heading): the walked value is vy */
         (void)accel;
         double hdg = s.ohd;
-        for (int f = 0; f < F; f++) {
-            hdg += d_heading;
-            hdg += 0.0 + p.heading_sigma * lane_bcast(zh, f);
-            if (lane == f) my_hd = hdg;
+#pragma unroll 1
+        for (int t = 0; t < F; t++) {
+            double h = dpp_mov<UAM_DPP_WAVE_SHR1>(hdg);
+            h += dh_l;
+            h += hnoise;
+            hdg = h;
         }
+        my_hd = hdg;
         double sn, cs;
         uam_sincos_k(my_hd, &sn, &cs);
-        double vyp = s.ovy, ox = s.ox, oy = s.oy;
-        for (int f = 0; f < F; f++) {
-            double spd = fmax(p.min_speed, fmin(vyp, p.max_speed));
-            spd += 0.0 + p.speed_sigma * lane_bcast(zs, f);
-            const double vx = spd * lane_bcast(cs, f), vy = spd * lane_bcast(sn, f);
-            ox += vx; oy += vy; vyp = vy;
-            if (lane == f) { my_sp = spd; my_vx = vx; my_vy = vy; my_ox = ox; my_oy = oy; }
+        const double sn_l = lane == 0 ? 1.0 : sn;
+        double vy = s.ovy, spd = 0.0;
+#pragma unroll 1
+        for (int t = 0; t < F; t++) {
+            double v = dpp_mov<UAM_DPP_WAVE_SHR1>(vy);
+            v = fmax(lo_l, fmin(v, hi_l));
+            v += snoise;
+            spd = v;
+            vy = v * sn_l;
         }
+        my_sp = spd; my_vx = spd * cs; my_vy = vy;
     }
-    const bool in_f = lane < F;
+    {   /* ---- positions in frame order, :83-86 */
+        const double ax = fr ? my_vx : 0.0, ay = fr ? my_vy : 0.0;
+        double ox = s.ox, oy = s.oy;
+#pragma unroll 1
+        for (int t = 0; t < F; t++) {
+            const double px = dpp_mov<UAM_DPP_WAVE_SHR1>(ox), py = dpp_mov<UAM_DPP_WAVE_SHR1>(oy);
+            ox = px + ax; oy = py + ay;
+        }
+        my_ox = ox; my_oy = oy;
+    }
     const bool wall = !(0.0 < my_ox && my_ox < p.W) || !(0.0 < my_oy && my_oy < p.H);
     const double gdx = my_ox - gx, gdy = my_oy - gy;
-    const unsigned long long wallm = __ballot(in_f && wall);
-    const unsigned long long goalm = __ballot(in_f && (gdx * gdx + gdy * gdy) < p.sep2);
+    const unsigned long long wallm = __ballot(fr && wall) >> 1;                           /* bit f = frame f */
+    const unsigned long long goalm = __ballot(fr && (gdx * gdx + gdy * gdy) < p.sep2) >> 1;
 
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     unsigned long long chg[K];            /* bit f: this intruder changes heading at frame f */
     if constexpr (!M4) {
-        double hcur[K];
+        /* (1) mark the changes, queue their words */
         int total = 0;
+        uint32_t thr_l[K];
 #pragma unroll
-        for (int k = 0; k < K; k++) { chg[k] = 0; hcur[k] = s.hd[k]; }
-        uint32_t hw[K][4];
-        for (int f = 0; f < F; f++) {
+        for (int k = 0; k < K; k++) {
+            chg[k] = 0;
+            thr_l[k] = (lane + 64 * k) < p.N ? (p.hc_thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p.hc_thr) : 0u;
+        }
+        const bool all_in = p.hc_thr > 0xFFFFFFFFull;     /* hc_prob >= 1: every word is a change, also 0xFFFFFFFF */
+        for (int f0 = 0; f0 < F; f0 += 4) {
+            uint32_t hw[K][4];
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const int i = lane + 64 * k;
-                bool c = false;
-                if (i < p.N) {
-                    if ((f & 3) == 0) mcts_philox(rng, (uint32_t)f >> 2, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
-                    const uint32_t w = (f & 2) ? ((f & 1) ? hw[k][3] : hw[k][2]) : ((f & 1) ? hw[k][1] : hw[k][0]);
-                    c = (unsigned long long)w < p.hc_thr;
-                    if (c) {
-                        const double ud = uam_u32d(w) / p.hc_prob;
-                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
-                        hcur[k] += deg * UAM_DEG2RAD;
-                        chg[k] |= 1ull << f;
+                hw[k][0] = hw[k][1] = hw[k][2] = hw[k][3] = 0;
+                if (i < p.N) mcts_philox(rng, (uint32_t)f0 >> 2, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int f = f0 + j;
+                if (f < F) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const uint32_t w = hw[k][j];
+                        const bool c = w < thr_l[k] || (all_in && thr_l[k] != 0u);
+                        const unsigned long long m = __ballot(c);
+                        if (c) {
+                            chg[k] |= 1ull << f;
+                            const int idx = total + __popcll(m & lt_mask);
+                            if (idx < QCAP) qw[idx] = w;
+                        }
+                        tab_m[f * K + k] = m;
+                        tab_b[f * K + k] = total;
+                        total += __popcll(m);
                     }
                 }
-                const unsigned long long m = __ballot(c);
-                if (c) {
-                    const int idx = total + __popcll(m & lt_mask);
-                    if (idx < QCAP) qh[idx] = hcur[k];
-                }
-                total += __popcll(m);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* (2) every lane accumulates its own changes in frame order */
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            unsigned long long pend = chg[k];
+            double hcur = s.hd[k];
+            while (__any(pend != 0ull)) {
+                if (pend != 0ull) {
+                    const int f = __builtin_ctzll(pend);
+                    pend &= pend - 1ull;
+                    const unsigned long long m = tab_m[f * K + k];
+                    const int idx = tab_b[f * K + k] + __popcll(m & lt_mask);
+                    const uint32_t w = idx < QCAP ? qw[idx] : mcts_hc_word(rng, f, lane + 64 * k);
+                    const double ud = uam_u32d(w) / p.hc_prob;
+                    const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                    hcur += deg * UAM_DEG2RAD;
+                    if (idx < QCAP) qh[idx] = hcur;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* (3) dense sincos of the queue */
         const int nq = total < QCAP ? total : QCAP;
         for (int j = lane; j < nq; j += 64) {
             double qsn, qcs;
@@ -271,9 +384,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                         s.vx[k] = sp[k] * qc[idx];
                         s.vy[k] = sp[k] * qs[idx];
                     } else {        /* queue overflow: redraw this frame's change and evaluate it here */
-                        uint32_t w4[4];
-                        mcts_philox(rng, (uint32_t)f >> 2, UAM_MPH_HEADCHG, (uint32_t)i, w4);
-                        const double ud = uam_u32d(w4[f & 3]) / p.hc_prob;
+                        const double ud = uam_u32d(mcts_hc_word(rng, f, i)) / p.hc_prob;
                         const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
                         s.hd[k] += deg * UAM_DEG2RAD;
                         double isn, ics;
@@ -287,7 +398,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         }
         if ((wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                        /* :94-96 */
         /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
-        const double oxf = lane_bcast(my_ox, f), oyf = lane_bcast(my_oy, f);
+        const double oxf = lane_bcast(my_ox, f + 1), oyf = lane_bcast(my_oy, f + 1);
         bool near = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -298,9 +409,9 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
         if (__any(near)) { flags = 2u; fe = f; break; }
         if ((goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                        /* :109-112 */
     }
-    s.ox = lane_bcast(my_ox, fe); s.oy = lane_bcast(my_oy, fe);
-    s.ovx = lane_bcast(my_vx, fe); s.ovy = lane_bcast(my_vy, fe);
-    s.osp = lane_bcast(my_sp, fe); s.ohd = lane_bcast(my_hd, fe);
+    s.ox = lane_bcast(my_ox, fe + 1); s.oy = lane_bcast(my_oy, fe + 1);
+    s.ovx = lane_bcast(my_vx, fe + 1); s.ovy = lane_bcast(my_vy, fe + 1);
+    s.osp = lane_bcast(my_sp, fe + 1); s.ohd = lane_bcast(my_hd, fe + 1);
     return flags;
 }
 
@@ -370,7 +481,7 @@ __device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const dou
 
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
 template <int K, int MODEL, int CAP>
-__device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP>& t, double* const qbuf)
+__device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP>& t, double* const qbuf, double* const ntab)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
@@ -394,9 +505,16 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
 
     MctsRng rng;
     rng.root = p.root_id0 + (uint32_t)root; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
+    MctsNoise nz;
+    nz.tab = ntab; nz.sim0 = 0; nz.nsim = 0; nz.mv0 = 0; nz.nmv = p.depth;
+    const int per_sim = p.depth * ((p.frames + 1) >> 1);       /* frame pairs a simulation can consume */
+    nz.per_move = per_sim > mcts_noise_cap(p);
+    const int sims_per_fill = nz.per_move ? 1 : mcts_noise_cap(p) / per_sim;
     int nn = 1;
     for (int sim = 0; sim < p.sims; sim++) {
         rng.sim = (uint32_t)sim; rng.mv = 0;
+        if (!nz.per_move && sim >= nz.sim0 + nz.nsim)
+            mcts_fill_noise(p, rng, nz, sim, sims_per_fill < p.sims - sim ? sims_per_fill : p.sims - sim, 0, p.depth, lane);
         /* ---- tree_policy */
         int v = 0;
         bool have_state = false;
@@ -409,7 +527,7 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
                 /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
                 const int k = 8 - nc;
                 mcts_load_node<K>(p, pint, pown, v, lane, s);
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s, qbuf);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s, qbuf, nz);
                 rng.mv = 1;
                 const int c = nn++;
                 depth = t.depth[v] + 1;
@@ -451,7 +569,7 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
                 uint32_t w4[4];
                 mcts_philox(rng, 0, UAM_MPH_ACTION, 0, w4);
                 const int a = (int)(((uint64_t)w4[0] * 9u) >> 32);          /* rollout_policy */
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s, qbuf);
+                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s, qbuf, nz);
                 rng.mv++;
                 depth++;
             }
@@ -501,7 +619,8 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree<UAM_MCTS_MAX_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
-    mcts_search<K, MODEL, UAM_MCTS_MAX_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6]);
+    __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
+    mcts_search<K, MODEL, UAM_MCTS_MAX_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
 }
 
 template <int MODEL>
@@ -510,7 +629,8 @@ uam_mcts_search_small_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree<UAM_MCTS_SMALL_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(1)];
-    mcts_search<1, MODEL, UAM_MCTS_SMALL_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6]);
+    __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
+    mcts_search<1, MODEL, UAM_MCTS_SMALL_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
 }
 
 /* one move() per state, no tree: parity / building block */
@@ -529,7 +649,10 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     MctsRng rng;
     rng.root = p.root_id0 + (uint32_t)root; rng.sim = p.sim_index; rng.mv = p.move_index; rng.k0 = p.seed_lo; rng.k1 = p.seed_hi;
     const int a0 = p.actions_in[2 * (size_t)root], a1 = p.actions_in[2 * (size_t)root + 1];
-    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s, queues[wv]);
+    __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
+    MctsNoise nz;
+    nz.tab = noise[wv]; nz.sim0 = 0; nz.nsim = 0; nz.mv0 = 0; nz.nmv = 1; nz.per_move = true;
+    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s, queues[wv], nz);
     double* out = p.next_out + (size_t)root * len;
 #pragma unroll
     for (int k = 0; k < K; k++) {
