@@ -94,27 +94,30 @@ extern "C" int uam_mcts_best_action(const uam_mcts_config* c, int device_id, con
     p.actions_out = actions_out; p.child_q_out = child_q_out; p.child_n_out = child_n_out;
     dim3 grid((B + UAM_MCTS_WAVES_PER_BLOCK - 1) / UAM_MCTS_WAVES_PER_BLOCK), block(64 * UAM_MCTS_WAVES_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
-#define UAM_MCTS_LAUNCH(KERNEL)                                                                             \
+    const bool pn = c->position_sigma != 0.0;     /* position noise is compiled out of the instances without it */
+#define UAM_MCTS_LAUNCH_K(KERNEL, MODEL, PN)                                                               \
+    switch (p.K) {                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1, MODEL, PN>), grid, block, 0, st, p); break;                      \
+    case 2: hipLaunchKernelGGL((KERNEL<2, MODEL, PN>), grid, block, 0, st, p); break;                      \
+    case 3: hipLaunchKernelGGL((KERNEL<3, MODEL, PN>), grid, block, 0, st, p); break;                      \
+    default: hipLaunchKernelGGL((KERNEL<4, MODEL, PN>), grid, block, 0, st, p); break;                     \
+    }
+#define UAM_MCTS_LAUNCH(KERNEL)                                                                            \
     if (c->model == UAM_MCTS_MODEL_STRAIGHT4) {                                                            \
-        switch (p.K) {                                                                                     \
-        case 1: hipLaunchKernelGGL((KERNEL<1, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
-        case 2: hipLaunchKernelGGL((KERNEL<2, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
-        case 3: hipLaunchKernelGGL((KERNEL<3, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;   \
-        default: hipLaunchKernelGGL((KERNEL<4, UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p); break;  \
-        }                                                                                                  \
+        if (pn) { UAM_MCTS_LAUNCH_K(KERNEL, UAM_MCTS_MODEL_STRAIGHT4, true) }                              \
+        else { UAM_MCTS_LAUNCH_K(KERNEL, UAM_MCTS_MODEL_STRAIGHT4, false) }                                \
     } else {                                                                                               \
-        switch (p.K) {                                                                                     \
-        case 1: hipLaunchKernelGGL((KERNEL<1, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
-        case 2: hipLaunchKernelGGL((KERNEL<2, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
-        case 3: hipLaunchKernelGGL((KERNEL<3, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;   \
-        default: hipLaunchKernelGGL((KERNEL<4, UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p); break;  \
-        }                                                                                                  \
+        if (pn) { UAM_MCTS_LAUNCH_K(KERNEL, UAM_MCTS_MODEL_RANDINTRU, true) }                              \
+        else { UAM_MCTS_LAUNCH_K(KERNEL, UAM_MCTS_MODEL_RANDINTRU, false) }                                \
     }
     if (p.K == 1 && p.cap <= UAM_MCTS_SMALL_NODES - 1) {      /* node ids < 127: the 4-waves/SIMD flavour */
-        if (c->model == UAM_MCTS_MODEL_STRAIGHT4)
-            hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_STRAIGHT4>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_RANDINTRU>), grid, block, 0, st, p);
+        if (c->model == UAM_MCTS_MODEL_STRAIGHT4) {
+            if (pn) hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_STRAIGHT4, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_STRAIGHT4, false>), grid, block, 0, st, p);
+        } else {
+            if (pn) hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_RANDINTRU, true>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((uam_mcts_search_small_kernel<UAM_MCTS_MODEL_RANDINTRU, false>), grid, block, 0, st, p);
+        }
     } else {
         UAM_MCTS_LAUNCH(uam_mcts_search_kernel)
     }
@@ -137,6 +140,7 @@ extern "C" int uam_mcts_move(const uam_mcts_config* c, int device_id, const doub
     p.sim_index = sim_index; p.move_index = move_index;
     dim3 grid((B + UAM_MCTS_WAVES_PER_BLOCK - 1) / UAM_MCTS_WAVES_PER_BLOCK), block(64 * UAM_MCTS_WAVES_PER_BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    const bool pn = c->position_sigma != 0.0;
     UAM_MCTS_LAUNCH(uam_mcts_move_kernel)
     HIP_TRY(hipGetLastError());
     return UAM_OK;

@@ -33,6 +33,11 @@
 #define UAM_MCTS_SMALL_NODES 128        /* tree capacity of the small instances (simulations <= 126) */
 #define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
 #define UAM_MCTS_WAVES_PER_BLOCK 2
+#ifndef UAM_MCTS_ABL
+#define UAM_MCTS_ABL 0                  /* development builds only: bit mask of sections executed TWICE (same results; the time added is the section's cost) */
+#endif
+__device__ __forceinline__ int mcts_opaque(int n) { asm volatile("" : "+s"(n)); return n; }
+#define UAM_MCTS_REPEAT(bit) for (int rep_ = 0, nrep_ = (UAM_MCTS_ABL & (bit)) ? mcts_opaque(2) : 1; rep_ < nrep_; rep_++)
 #ifndef UAM_MCTS_PHILOX_WIDE
 #define UAM_MCTS_PHILOX_WIDE 1          /* 64-bit products (v_mad_u64_u32): half the quarter-rate multiplies of a block */
 #endif
@@ -64,6 +69,8 @@ struct UamMctsParams {
     double* reward_out;                  /* [B] */
 };
 
+typedef const __attribute__((address_space(4))) UamMctsParams MctsParamsK;   /* the block where it lives: the kernarg segment */
+
 /* tree bookkeeping of one root (one wave) in LDS: 38 B per node */
 template <int CAP> struct MctsTree {
     double n[CAP], q[CAP], rew[CAP];
@@ -90,9 +97,14 @@ __device__ __forceinline__ double lane_bcast(double v, int l)
 }
 __device__ __forceinline__ int lane_bcast(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
+/* The key is pinned to scalar registers at every call: its ten round keys are then scalar additions next to their use.
+ * Left alone, the compiler computes the 18 derived round keys once, up front, and keeps them in registers for the
+ * whole search. */
 __device__ __forceinline__ void mcts_philox(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx, uint32_t* w)
 {
-    uam_philox_t<UAM_MCTS_PHILOX_WIDE != 0>(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, r.k0, r.k1, w);
+    uint32_t k0 = r.k0, k1 = r.k1;
+    asm volatile("" : "+s"(k0), "+s"(k1));
+    uam_philox_t<UAM_MCTS_PHILOX_WIDE != 0>(r.root, (r.sim << 4) | r.mv, (framepair << 8) | purpose, idx, k0, k1, w);
 }
 
 __device__ __forceinline__ void mcts_normals(const MctsRng& r, uint32_t framepair, uint32_t purpose, uint32_t idx,
@@ -122,9 +134,9 @@ struct MctsNoise {
     bool per_move;                        /* depth x frame pairs exceed the table: refill before every move */
 };
 
-__device__ __forceinline__ int mcts_noise_cap(const UamMctsParams& p) { return p.speed_sigma != 0.0 ? 32 : 64; }
+__device__ __forceinline__ int mcts_noise_cap(MctsParamsK& p) { return p.speed_sigma != 0.0 ? 32 : 64; }
 
-__device__ inline void mcts_fill_noise(const UamMctsParams& p, const MctsRng& base, MctsNoise& nz, const int sim0,
+__device__ inline void mcts_fill_noise(MctsParamsK& p, const MctsRng& base, MctsNoise& nz, const int sim0,
                                        const int nsim, const int mv0, const int nmv, const int lane)
 {
     const int FP = (p.frames + 1) >> 1, per = nmv * FP, tot = nsim * per;
@@ -155,47 +167,55 @@ __device__ __forceinline__ uint32_t mcts_hc_word(const MctsRng& rng, const int f
     return w4[f & 3];
 }
 
-/* SingleAircraftState.move, nodes_single_randintru.py:39-114.  `sp` = per-slot intruder speed (constant
+/* The parameter block as a section of the move reads it: afresh from the kernarg segment (scalar loads through the
+ * scalar cache), behind an opaque pointer, at the point of use.  The by-value copy keeps ~70 SGPRs of parameters live
+ * across the whole search on top of the wave-uniform search state; gfx950 has 102, and what does not fit is spilled
+ * to VGPR LANES — every reload a v_readlane, i.e. a vector instruction: the frame loop reloaded ~30 SGPRs per frame,
+ * about as many vector instructions as its arithmetic. */
+__device__ __forceinline__ MctsParamsK& mcts_params()
+{
+    MctsParamsK* pp = (MctsParamsK*)__builtin_amdgcn_kernarg_segment_ptr();     /* constant address space: s_load */
+    asm volatile("" : "+s"(pp) :: "memory");
+    return *pp;
+}
+
+/* lane's rank among the set bits of a ballot, added to `base` (v_mbcnt_lo / v_mbcnt_hi) */
+__device__ __forceinline__ int mcts_rank(unsigned long long m, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)base));
+}
+
+__device__ __forceinline__ void mcts_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* SingleAircraftState.move, nodes_single_randintru.py:39-114, in sections.  `sp` = per-slot intruder speed (constant
  * over the tree).  Returns flag bits: 1 hit_wall, 2 conflict, 4 reach_goal.
  *
- * The ownship's trajectory over the move's frames does not depend on the intruders, so it is computed up front with
- * the frames spread over lanes: LANE f + 1 HOLDS FRAME f, lane 0 the state before the move.  The sincos of every
- * frame's heading is evaluated once, in parallel.  The recurrences (heading: two additions a frame; speed: addition,
- * clamp, addition; position: one addition per axis) are WALKED through the lanes: F times, every lane takes its left
+ * Section A, the ownship's trajectory.  It does not depend on the intruders, so it is computed up front with the
+ * frames spread over lanes: LANE f + 1 HOLDS FRAME f, lane 0 the state before the move.  The sincos of every frame's
+ * heading is evaluated once, in parallel.  The recurrences (heading: two additions a frame; speed: addition, clamp,
+ * addition; position: one addition per axis) are WALKED through the lanes: F times, every lane takes its left
  * neighbour's value (DPP wave_shr:1, no LDS, no scalar round trip) and applies its own frame's update — after step
  * t lanes 0..t+1 are final and stay so, because they recompute the same value from final inputs.  Lane 0's update is
  * the identity (increment 0, clamp to +-inf, noise 0), so no lane needs a select.  Each frame's value is produced
  * by the reference's operations in the reference's order on the reference's inputs: every rounding is the
- * reference's.  Four VALU instructions per double and frame instead of readlane broadcasts, multiplies and selects
- * (~9).  Needs frames <= 63. */
-/* Heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on positions, so all of
- * a move's changes are settled in a PRE-PASS in three steps.  (1) Per frame, one compare per lane marks the changes
- * (bit f of chg), the change's word goes into a wave-level LDS queue (slot = running ballot rank, frame-major) and
- * the ballot and its running base are noted per frame — no arithmetic under the divergent branch.  (2) Every lane
- * walks ITS OWN changes in frame order (a loop over the set bits of chg: as many trips as the busiest lane has
- * changes, ~3-4 of 10 frames at the shipped 10 %, instead of one divergent body per frame), accumulates its heading
- * and leaves it in the queue.  (3) The queue's sincos are evaluated DENSELY (lane j takes entry j, j + 64, ...: ~N
- * entries per move instead of F sparse evaluations with ~10 % of the lanes active).  The frame loop then picks its
- * (heading, cos, sin) up by recomputing the same ballot rank.  Entries beyond the queue's capacity (never at the
- * shipped rate, but possible) are evaluated in place. */
-#define UAM_MCTS_QCAP(K) (128 * (K))
+ * reference's.  Needs frames <= 63. */
+struct MctsOwnTraj {
+    double sp, hd, vx, vy, ox, oy;       /* lane f + 1: the ownship after frame f */
+    unsigned long long wallm, goalm;     /* bit f: frame f leaves the map / reaches the goal */
+};
 #define UAM_DPP_WAVE_SHR1 0x138
 
 template <int K, int MODEL>
-__device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng, const int lane, const double* sp,
-                                     const double gx, const double gy, const int a0, const int a1, MctsState<K>& s,
-                                     double* qbuf, MctsNoise& nz)
+__device__ __forceinline__ void mcts_own_traj(const MctsRng& rng, const int lane, const double gx, const double gy, const int a0,
+                                              const int a1, const MctsState<K>& s, MctsNoise& nz, MctsOwnTraj& o)
 {
     constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
-    constexpr int QCAP = UAM_MCTS_QCAP(K);
-    double* const qh = qbuf;              /* heading after the change */
-    double* const qc = qbuf + QCAP;       /* its cosine */
-    double* const qs = qbuf + 2 * QCAP;   /* its sine */
-    /* scratch of the pre-pass, dead before the dense sincos writes qc / qs: per (frame, slot) ballot and base */
-    unsigned long long* const tab_m = (unsigned long long*)qc;     /* [F * K] <= 63 K * 8 B */
-    int* const tab_b = (int*)(tab_m + 64 * K);                     /* [F * K]: 512 K + 256 K <= 1024 K B */
-    uint32_t* const qw = (uint32_t*)qs;                            /* [QCAP] the changes' words */
-    (void)qh; (void)qc; (void)qs; (void)tab_m; (void)tab_b; (void)qw;
+    MctsParamsK& p = mcts_params();
     const int F = p.frames;
     const double d_heading = (double)(a0 - 1) * p.d_heading;
     const double accel = (double)(a1 - 1) * p.d_speed;
@@ -214,11 +234,11 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
     const double snoise = fr ? 0.0 + p.speed_sigma * zs : 0.0;
     const double dh_l = lane == 0 ? 0.0 : d_heading;
     const double lo_l = lane == 0 ? -__builtin_inf() : p.min_speed, hi_l = lane == 0 ? __builtin_inf() : p.max_speed;
-    double my_sp, my_hd, my_vx, my_vy, my_ox, my_oy;
     if constexpr (!M4) {
         /* ---- speed / heading recurrences in frame order, :73-79 (speed first, then heading) */
         const double ac_l = lane == 0 ? 0.0 : accel;
         double spd = s.osp, hdg = s.ohd;
+        UAM_MCTS_REPEAT(8)
 #pragma unroll 1
         for (int t = 0; t < F; t++) {
             double v = dpp_mov<UAM_DPP_WAVE_SHR1>(spd), h = dpp_mov<UAM_DPP_WAVE_SHR1>(hdg);
@@ -229,11 +249,14 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
             h += hnoise;
             spd = v; hdg = h;
         }
-        my_sp = spd; my_hd = hdg;
+        o.sp = spd; o.hd = hdg;
         /* ---- every frame's velocity at once, :81-82 */
         double sn, cs;
-        uam_sincos_k(my_hd, &sn, &cs);
-        my_vx = my_sp * cs; my_vy = my_sp * sn;
+        UAM_MCTS_REPEAT(16) {
+            if (rep_) asm volatile("" : "+v"(o.hd));
+            uam_sincos_k(o.hd, &sn, &cs);
+        }
+        o.vx = o.sp * cs; o.vy = o.sp * sn;
     } else {
         /* nodes_single.py:59-71: the heading recurrence is independent of the speed, so every frame's heading
          * and its sincos come first; the speed is then re-derived each frame from the previous frame's vy
@@ -247,9 +270,9 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
             h += hnoise;
             hdg = h;
         }
-        my_hd = hdg;
+        o.hd = hdg;
         double sn, cs;
-        uam_sincos_k(my_hd, &sn, &cs);
+        uam_sincos_k(o.hd, &sn, &cs);
         const double sn_l = lane == 0 ? 1.0 : sn;
         double vy = s.ovy, spd = 0.0;
 #pragma unroll 1
@@ -260,42 +283,70 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
             spd = v;
             vy = v * sn_l;
         }
-        my_sp = spd; my_vx = spd * cs; my_vy = vy;
+        o.sp = spd; o.vx = spd * cs; o.vy = vy;
     }
     {   /* ---- positions in frame order, :83-86 */
-        const double ax = fr ? my_vx : 0.0, ay = fr ? my_vy : 0.0;
+        const double ax = fr ? o.vx : 0.0, ay = fr ? o.vy : 0.0;
         double ox = s.ox, oy = s.oy;
+        UAM_MCTS_REPEAT(8)
 #pragma unroll 1
         for (int t = 0; t < F; t++) {
             const double px = dpp_mov<UAM_DPP_WAVE_SHR1>(ox), py = dpp_mov<UAM_DPP_WAVE_SHR1>(oy);
             ox = px + ax; oy = py + ay;
         }
-        my_ox = ox; my_oy = oy;
+        o.ox = ox; o.oy = oy;
     }
-    const bool wall = !(0.0 < my_ox && my_ox < p.W) || !(0.0 < my_oy && my_oy < p.H);
-    const double gdx = my_ox - gx, gdy = my_oy - gy;
-    const unsigned long long wallm = __ballot(fr && wall) >> 1;                           /* bit f = frame f */
-    const unsigned long long goalm = __ballot(fr && (gdx * gdx + gdy * gdy) < p.sep2) >> 1;
+    const bool wall = !(0.0 < o.ox && o.ox < p.W) || !(0.0 < o.oy && o.oy < p.H);
+    const double gdx = o.ox - gx, gdy = o.oy - gy;
+    o.wallm = __ballot(fr && wall) >> 1;                                                 /* bit f = frame f */
+    o.goalm = __ballot(fr && (gdx * gdx + gdy * gdy) < p.sep2) >> 1;
+}
 
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    unsigned long long chg[K];            /* bit f: this intruder changes heading at frame f */
-    if constexpr (!M4) {
+/* Section B, heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on
+ * positions, so all of a move's changes are settled in a PRE-PASS in three steps.  (1) Per frame, one compare per lane
+ * marks the changes (bit f of chg), the change's word goes into a wave-level LDS queue (slot = running ballot rank,
+ * frame-major) and the ballot and its running base are noted per frame — no arithmetic under the divergent branch.
+ * (2) Every lane walks ITS OWN changes in frame order (a loop over the set bits of chg: as many trips as the busiest
+ * lane has changes, ~3-4 of 10 frames at the shipped 10 %, instead of one divergent body per frame), accumulates its
+ * heading and leaves it in the queue.  (3) The queue's sincos are evaluated DENSELY (lane j takes entry j, j + 64,
+ * ...: ~N entries per move instead of F sparse evaluations with ~10 % of the lanes active).  The frame loop then
+ * picks its (heading, cos, sin) up by recomputing the same ballot rank.  A move with more changes than the queue
+ * holds (never at the shipped rate, but possible) skips (2) and (3) and takes the slow frame loop, which evaluates
+ * every change in place.  Returns the number of changes. */
+#define UAM_MCTS_QCAP(K) (128 * (K))
+
+template <int K>
+__device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const int lane, const double* hd0, double* const qbuf,
+                                                    unsigned long long* chg)
+{
+    constexpr int QCAP = UAM_MCTS_QCAP(K);
+    double* const qh = qbuf;              /* heading after the change */
+    double* const qc = qbuf + QCAP;       /* its cosine */
+    double* const qs = qbuf + 2 * QCAP;   /* its sine */
+    /* scratch of steps (1)-(2), dead before the dense sincos writes qc / qs: per (frame, slot) ballot and base */
+    unsigned long long* const tab_m = (unsigned long long*)qc;     /* [F * K] <= 63 K * 8 B */
+    int* const tab_b = (int*)(tab_m + 64 * K);                     /* [F * K]: 512 K + 256 K <= 1024 K B */
+    uint32_t* const qw = (uint32_t*)qs;                            /* [QCAP] the changes' words */
+    int total = 0;
+    {
+        MctsParamsK& p = mcts_params();
+        const int F = p.frames;
         /* (1) mark the changes, queue their words */
-        int total = 0;
         uint32_t thr_l[K];
+        const bool all_in = p.hc_thr > 0xFFFFFFFFull;     /* hc_prob >= 1: every word is a change, also 0xFFFFFFFF */
+        UAM_MCTS_REPEAT(1) {
+        total = 0;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             chg[k] = 0;
-            thr_l[k] = (lane + 64 * k) < p.N ? (p.hc_thr > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)p.hc_thr) : 0u;
+            thr_l[k] = (lane + 64 * k) < p.N ? (all_in ? 0xFFFFFFFFu : (uint32_t)p.hc_thr) : 0u;
         }
-        const bool all_in = p.hc_thr > 0xFFFFFFFFull;     /* hc_prob >= 1: every word is a change, also 0xFFFFFFFF */
         for (int f0 = 0; f0 < F; f0 += 4) {
             uint32_t hw[K][4];
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const int i = lane + 64 * k;
                 hw[k][0] = hw[k][1] = hw[k][2] = hw[k][3] = 0;
-                if (i < p.N) mcts_philox(rng, (uint32_t)f0 >> 2, UAM_MPH_HEADCHG, (uint32_t)i, hw[k]);
+                if (thr_l[k] != 0u) mcts_philox(rng, (uint32_t)f0 >> 2, UAM_MPH_HEADCHG, (uint32_t)(lane + 64 * k), hw[k]);
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -308,7 +359,7 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                         const unsigned long long m = __ballot(c);
                         if (c) {
                             chg[k] |= 1ull << f;
-                            const int idx = total + __popcll(m & lt_mask);
+                            const int idx = mcts_rank(m, total);
                             if (idx < QCAP) qw[idx] = w;
                         }
                         tab_m[f * K + k] = m;
@@ -318,54 +369,132 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if (total > QCAP) return total;
+    mcts_wave_sync();
+    {
+        MctsParamsK& p = mcts_params();
+        const double hc_prob = p.hc_prob, hc_max = p.hc_max_deg;
         /* (2) every lane accumulates its own changes in frame order */
+        UAM_MCTS_REPEAT(2)
 #pragma unroll
         for (int k = 0; k < K; k++) {
             unsigned long long pend = chg[k];
-            double hcur = s.hd[k];
+            double hcur = hd0[k];
             while (__any(pend != 0ull)) {
                 if (pend != 0ull) {
                     const int f = __builtin_ctzll(pend);
                     pend &= pend - 1ull;
-                    const unsigned long long m = tab_m[f * K + k];
-                    const int idx = tab_b[f * K + k] + __popcll(m & lt_mask);
-                    const uint32_t w = idx < QCAP ? qw[idx] : mcts_hc_word(rng, f, lane + 64 * k);
-                    const double ud = uam_u32d(w) / p.hc_prob;
-                    const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                    const int idx = mcts_rank(tab_m[f * K + k], tab_b[f * K + k]);
+                    const double ud = uam_u32d(qw[idx]) / hc_prob;
+                    const double deg = -hc_max + (hc_max - (-hc_max)) * ud;
                     hcur += deg * UAM_DEG2RAD;
-                    if (idx < QCAP) qh[idx] = hcur;
+                    qh[idx] = hcur;
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        /* (3) dense sincos of the queue */
-        const int nq = total < QCAP ? total : QCAP;
-        for (int j = lane; j < nq; j += 64) {
-            double qsn, qcs;
-            uam_sincos_k(qh[j], &qsn, &qcs);
-            qc[j] = qcs; qs[j] = qsn;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    mcts_wave_sync();
+    /* (3) dense sincos of the queue */
+    UAM_MCTS_REPEAT(4)
+    for (int j = lane; j < total; j += 64) {
+        double qsn, qcs;
+        uam_sincos_k(qh[j], &qsn, &qcs);
+        qc[j] = qcs; qs[j] = qsn;
+    }
+    mcts_wave_sync();
+    return total;
+}
 
+/* Section C, the frames: intruders move, changed headings are picked up from the queue, the move ends at the first
+ * frame that leaves the map, comes within minimum_separation of an intruder or reaches the goal.  PN: position noise
+ * is compiled in (position_sigma != 0; the shipped config has 0). */
+template <int K, int MODEL, bool PN>
+__device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int lane, const double* sp, MctsState<K>& s,
+                                                const MctsOwnTraj& o, const unsigned long long* chg, const double* const qbuf,
+                                                int& fe)
+{
+    constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
+    constexpr int QCAP = UAM_MCTS_QCAP(K);
+    const double* const qh = qbuf;
+    const double* const qc = qbuf + QCAP;
+    const double* const qs = qbuf + 2 * QCAP;
+    (void)qh; (void)qc; (void)qs; (void)chg; (void)sp;
+    MctsParamsK& p = mcts_params();
+    const int F = p.frames;
+    const double sep2 = p.sep2;
+    unsigned long long inm[K];            /* lanes whose slot holds a simulated intruder */
+#pragma unroll
+    for (int k = 0; k < K; k++) inm[k] = __ballot(lane + 64 * k < p.Nsim);
+    double psig = 0.0;
+    if constexpr (PN) psig = p.position_sigma;
     uint32_t flags = 0;
-    int fe = F - 1;
+    fe = F - 1;
     int qbase = 0;
     for (int f = 0; f < F; f++) {
         /* ---- intruders: position += velocity (+ noise), Bernoulli heading change, :54-70 */
 #pragma unroll
         for (int k = 0; k < K; k++) {
+            double nx_ = 0.0, ny_ = 0.0;
+            if constexpr (PN) {
+                if ((inm[k] >> lane) & 1ull) {
+                    double z0, z1;
+                    mcts_normals(rng, (uint32_t)f, UAM_MPH_POS, (uint32_t)(lane + 64 * k), z0, z1);
+                    nx_ = 0.0 + psig * z0;
+                    ny_ = 0.0 + psig * z1;
+                }
+            }
+            /* (slots beyond Nsim hold zeros or, STRAIGHT4's unmoved last intruder, are never read back as moved:
+             * they are integrated under the lane mask like the rest) */
+            if ((inm[k] >> lane) & 1ull) {
+                s.x[k] += s.vx[k] + nx_;
+                s.y[k] += s.vy[k] + ny_;
+            }
+            if constexpr (!M4) {
+                const bool c = (chg[k] >> f) & 1ull;
+                const unsigned long long m = __ballot(c);
+                if (c) {
+                    const int idx = mcts_rank(m, qbase);
+                    s.hd[k] = qh[idx];
+                    s.vx[k] = sp[k] * qc[idx];
+                    s.vy[k] = sp[k] * qs[idx];
+                }
+                qbase += __popcll(m);
+            }
+        }
+        if ((o.wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                      /* :94-96 */
+        /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
+        const double oxf = lane_bcast(o.ox, f + 1), oyf = lane_bcast(o.oy, f + 1);
+        unsigned long long nearm = 0ull;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const double dx = s.x[k] - oxf, dy = s.y[k] - oyf;
+            nearm |= __ballot((dx * dx + dy * dy) < sep2) & inm[k];
+        }
+        if (nearm != 0ull) { flags = 2u; fe = f; break; }
+        if ((o.goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                      /* :109-112 */
+    }
+    return flags;
+}
+
+/* Section C for a move with more heading changes than the queue holds: every change is redrawn and evaluated in
+ * place, frame by frame (one sparse sincos per frame).  Same values as the queue's. */
+template <int K, bool PN>
+__device__ __forceinline__ uint32_t mcts_frames_slow(const MctsRng& rng, const int lane, const double* sp, MctsState<K>& s,
+                                                  const MctsOwnTraj& o, const unsigned long long* chg, int& fe)
+{
+    MctsParamsK& p = mcts_params();
+    const int F = p.frames;
+    uint32_t flags = 0;
+    fe = F - 1;
+    for (int f = 0; f < F; f++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
             const int i = lane + 64 * k;
             if (i < p.Nsim) {
                 double nx_ = 0.0, ny_ = 0.0;
-                if (p.position_sigma != 0.0) {
+                if constexpr (PN) {
                     double z0, z1;
                     mcts_normals(rng, (uint32_t)f, UAM_MPH_POS, (uint32_t)i, z0, z1);
                     nx_ = 0.0 + p.position_sigma * z0;
@@ -374,50 +503,53 @@ __device__ inline uint32_t mcts_move(const UamMctsParams& p, const MctsRng& rng,
                 s.x[k] += s.vx[k] + nx_;
                 s.y[k] += s.vy[k] + ny_;
             }
-            if constexpr (!M4) {
-                const bool c = (chg[k] >> f) & 1ull;
-                const unsigned long long m = __ballot(c);
-                if (c) {
-                    const int idx = qbase + __popcll(m & lt_mask);
-                    if (idx < QCAP) {
-                        s.hd[k] = qh[idx];
-                        s.vx[k] = sp[k] * qc[idx];
-                        s.vy[k] = sp[k] * qs[idx];
-                    } else {        /* queue overflow: redraw this frame's change and evaluate it here */
-                        const double ud = uam_u32d(mcts_hc_word(rng, f, i)) / p.hc_prob;
-                        const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
-                        s.hd[k] += deg * UAM_DEG2RAD;
-                        double isn, ics;
-                        uam_sincos_k(s.hd[k], &isn, &ics);
-                        s.vx[k] = sp[k] * ics;
-                        s.vy[k] = sp[k] * isn;
-                    }
-                }
-                qbase += __popcll(m);
+            if ((chg[k] >> f) & 1ull) {
+                const double ud = uam_u32d(mcts_hc_word(rng, f, i)) / p.hc_prob;
+                const double deg = -p.hc_max_deg + (p.hc_max_deg - (-p.hc_max_deg)) * ud;
+                s.hd[k] += deg * UAM_DEG2RAD;
+                double isn, ics;
+                uam_sincos_k(s.hd[k], &isn, &ics);
+                s.vx[k] = sp[k] * ics;
+                s.vy[k] = sp[k] * isn;
             }
         }
-        if ((wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                        /* :94-96 */
-        /* any intruder within minimum_separation (sqrt(d2) < thr  <=>  d2 < T2), :98-104 */
-        const double oxf = lane_bcast(my_ox, f + 1), oyf = lane_bcast(my_oy, f + 1);
+        if ((o.wallm >> f) & 1ull) { flags = 1u; fe = f; break; }
+        const double oxf = lane_bcast(o.ox, f + 1), oyf = lane_bcast(o.oy, f + 1);
         bool near = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const int i = lane + 64 * k;
             const double dx = s.x[k] - oxf, dy = s.y[k] - oyf;
-            near = near || (i < p.Nsim && (dx * dx + dy * dy) < p.sep2);
+            near = near || (lane + 64 * k < p.Nsim && (dx * dx + dy * dy) < p.sep2);
         }
         if (__any(near)) { flags = 2u; fe = f; break; }
-        if ((goalm >> f) & 1ull) { flags = 4u; fe = f; break; }                                        /* :109-112 */
+        if ((o.goalm >> f) & 1ull) { flags = 4u; fe = f; break; }
     }
-    s.ox = lane_bcast(my_ox, fe + 1); s.oy = lane_bcast(my_oy, fe + 1);
-    s.ovx = lane_bcast(my_vx, fe + 1); s.ovy = lane_bcast(my_vy, fe + 1);
-    s.osp = lane_bcast(my_sp, fe + 1); s.ohd = lane_bcast(my_hd, fe + 1);
+    return flags;
+}
+
+template <int K, int MODEL, bool PN>
+__device__ __forceinline__ uint32_t mcts_move(const MctsRng& rng, const int lane, const double* sp, const double gx, const double gy,
+                                              const int a0, const int a1, MctsState<K>& s, double* qbuf, MctsNoise& nz)
+{
+    constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
+    MctsOwnTraj o;
+    mcts_own_traj<K, MODEL>(rng, lane, gx, gy, a0, a1, s, nz, o);
+    unsigned long long chg[K];
+    int total = 0;
+    if constexpr (!M4) total = mcts_heading_prepass<K>(rng, lane, s.hd, qbuf, chg);
+    uint32_t flags;
+    int fe;
+    if (M4 || total <= UAM_MCTS_QCAP(K)) flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbuf, fe);
+    else flags = mcts_frames_slow<K, PN>(rng, lane, sp, s, o, chg, fe);
+    s.ox = lane_bcast(o.ox, fe + 1); s.oy = lane_bcast(o.oy, fe + 1);
+    s.ovx = lane_bcast(o.vx, fe + 1); s.ovy = lane_bcast(o.vy, fe + 1);
+    s.osp = lane_bcast(o.sp, fe + 1); s.ohd = lane_bcast(o.hd, fe + 1);
     return flags;
 }
 
 /* SingleAircraftState.reward, :25-32 */
 template <int K>
-__device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const MctsState<K>& s, double gx, double gy, uint32_t flags)
+__device__ __forceinline__ double mcts_reward(MctsParamsK& p, const MctsState<K>& s, double gx, double gy, uint32_t flags)
 {
     if (flags & 3u) return 0.0;
     if (flags & 4u) return 1.0;
@@ -426,7 +558,7 @@ __device__ __forceinline__ double mcts_reward(const UamMctsParams& p, const Mcts
 }
 
 template <int K>
-__device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const double* root, int lane, MctsState<K>& s, double* sp,
+__device__ __forceinline__ void mcts_load_root(MctsParamsK& p, const double* root, int lane, MctsState<K>& s, double* sp,
                                                double& gx, double& gy)
 {
 #pragma unroll
@@ -444,17 +576,15 @@ __device__ __forceinline__ void mcts_load_root(const UamMctsParams& p, const dou
 }
 
 template <int K>
-__device__ __forceinline__ void mcts_store_node(const UamMctsParams& p, double* pint, double* pown, int node, int lane,
-                                                const MctsState<K>& s)
+__device__ __forceinline__ void mcts_store_node(double* pint, double* pown, int node, int lane, const MctsState<K>& s)
 {
-    double* b = pint + (size_t)node * 5 * p.Npad;
+    constexpr int NP = 64 * K;            /* = UamMctsParams::Npad */
+    double* b = pint + (size_t)node * 5 * NP;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int i = lane + 64 * k;
-        if (i < p.Npad) {
-            b[i] = s.x[k]; b[p.Npad + i] = s.y[k]; b[2 * p.Npad + i] = s.vx[k]; b[3 * p.Npad + i] = s.vy[k];
-            b[4 * p.Npad + i] = s.hd[k];
-        }
+        b[i] = s.x[k]; b[NP + i] = s.y[k]; b[2 * NP + i] = s.vx[k]; b[3 * NP + i] = s.vy[k];
+        b[4 * NP + i] = s.hd[k];
     }
     if (lane < 6) {
         const double v = lane == 0 ? s.ox : lane == 1 ? s.oy : lane == 2 ? s.ovx : lane == 3 ? s.ovy : lane == 4 ? s.osp : s.ohd;
@@ -463,28 +593,27 @@ __device__ __forceinline__ void mcts_store_node(const UamMctsParams& p, double* 
 }
 
 template <int K>
-__device__ __forceinline__ void mcts_load_node(const UamMctsParams& p, const double* pint, const double* pown, int node,
-                                               int lane, MctsState<K>& s)
+__device__ __forceinline__ void mcts_load_node(const double* pint, const double* pown, int node, int lane, MctsState<K>& s)
 {
-    const double* b = pint + (size_t)node * 5 * p.Npad;
+    constexpr int NP = 64 * K;
+    const double* b = pint + (size_t)node * 5 * NP;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const int i = lane + 64 * k;
-        const bool ok = i < p.Npad;
-        const int j = ok ? i : 0;
-        s.x[k] = b[j]; s.y[k] = b[p.Npad + j]; s.vx[k] = b[2 * p.Npad + j]; s.vy[k] = b[3 * p.Npad + j];
-        s.hd[k] = b[4 * p.Npad + j];
+        const int j = lane + 64 * k;
+        s.x[k] = b[j]; s.y[k] = b[NP + j]; s.vx[k] = b[2 * NP + j]; s.vy[k] = b[3 * NP + j];
+        s.hd[k] = b[4 * NP + j];
     }
     const double* o = pown + (size_t)node * 8;
     s.ox = o[0]; s.oy = o[1]; s.ovx = o[2]; s.ovy = o[3]; s.osp = o[4]; s.ohd = o[5];
 }
 
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
-template <int K, int MODEL, int CAP>
-__device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP>& t, double* const qbuf, double* const ntab)
+template <int K, int MODEL, bool PN, int CAP>
+__device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf, double* const ntab)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
+    MctsParamsK& p = mcts_params();
     if (root >= p.B) return;
     double* pint = p.pool_int + (size_t)root * p.cap * 5 * p.Npad;
     double* pown = p.pool_own + (size_t)root * p.cap * 8;
@@ -493,7 +622,7 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
     double sp[K];
     double gx, gy;
     mcts_load_root<K>(p, p.roots + (size_t)root * (p.width * p.N + 8), lane, rs, sp, gx, gy);
-    mcts_store_node<K>(p, pint, pown, 0, lane, rs);
+    mcts_store_node<K>(pint, pown, 0, lane, rs);
     for (int i = lane; i < p.cap; i += 64) {
         t.n[i] = 0.0; t.q[i] = 0.0; t.rew[i] = 0.0;
         t.parent[i] = 255; t.nchild[i] = 0; t.depth[i] = 0; t.term[i] = 0; t.act[i] = 0;
@@ -511,10 +640,13 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
     nz.per_move = per_sim > mcts_noise_cap(p);
     const int sims_per_fill = nz.per_move ? 1 : mcts_noise_cap(p) / per_sim;
     int nn = 1;
-    for (int sim = 0; sim < p.sims; sim++) {
+    const int sims = p.sims, max_depth = p.depth;
+    const double c_param = p.c_param;
+    for (int sim = 0; sim < sims; sim++) {
         rng.sim = (uint32_t)sim; rng.mv = 0;
         if (!nz.per_move && sim >= nz.sim0 + nz.nsim)
-            mcts_fill_noise(p, rng, nz, sim, sims_per_fill < p.sims - sim ? sims_per_fill : p.sims - sim, 0, p.depth, lane);
+            UAM_MCTS_REPEAT(64)
+            mcts_fill_noise(mcts_params(), rng, nz, sim, sims_per_fill < sims - sim ? sims_per_fill : sims - sim, 0, max_depth, lane);
         /* ---- tree_policy */
         int v = 0;
         bool have_state = false;
@@ -526,17 +658,17 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
             if (nc < 9) {
                 /* expand: untried_actions.pop() takes the tail of product(range(3), repeat=2) */
                 const int k = 8 - nc;
-                mcts_load_node<K>(p, pint, pown, v, lane, s);
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, k / 3, k % 3, s, qbuf, nz);
+                mcts_load_node<K>(pint, pown, v, lane, s);
+                flags = mcts_move<K, MODEL, PN>(rng, lane, sp, gx, gy, k / 3, k % 3, s, qbuf, nz);
                 rng.mv = 1;
                 const int c = nn++;
                 depth = t.depth[v] + 1;
-                const bool term = flags != 0 || depth == p.depth;
+                const bool term = flags != 0 || depth == max_depth;
                 t.parent[c] = (uint8_t)v; t.depth[c] = (uint8_t)depth; t.act[c] = (uint8_t)k; t.term[c] = term ? 1 : 0;
                 t.child[v][nc] = (uint8_t)c;
                 t.nchild[v] = (uint8_t)(nc + 1);
-                if (term) t.rew[c] = mcts_reward<K>(p, s, gx, gy, flags);
-                else mcts_store_node<K>(p, pint, pown, c, lane, s);     /* only expandable nodes keep their state */
+                if (term) t.rew[c] = mcts_reward<K>(mcts_params(), s, gx, gy, flags);
+                else mcts_store_node<K>(pint, pown, c, lane, s);     /* only expandable nodes keep their state */
                 v = c;
                 have_state = true;
                 break;
@@ -547,7 +679,7 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
             if (lane < 9) {
                 const int c = t.child[v][lane];
                 const double cn = t.n[c];
-                w = (t.q[c] / cn) + p.c_param * __builtin_sqrt((2 * logn / cn));
+                w = (t.q[c] / cn) + c_param * __builtin_sqrt((2 * logn / cn));
             }
             int best = lane;
 #pragma unroll
@@ -565,15 +697,15 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
             r = t.rew[v];
         } else {
             (void)have_state;
-            while (flags == 0 && depth < p.depth) {
+            while (flags == 0 && depth < max_depth) {
                 uint32_t w4[4];
                 mcts_philox(rng, 0, UAM_MPH_ACTION, 0, w4);
                 const int a = (int)(((uint64_t)w4[0] * 9u) >> 32);          /* rollout_policy */
-                flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a / 3, a % 3, s, qbuf, nz);
+                flags = mcts_move<K, MODEL, PN>(rng, lane, sp, gx, gy, a / 3, a % 3, s, qbuf, nz);
                 rng.mv++;
                 depth++;
             }
-            r = mcts_reward<K>(p, s, gx, gy, flags);
+            r = mcts_reward<K>(mcts_params(), s, gx, gy, flags);
         }
         /* ---- backpropagate (every lane writes the same values: wave-uniform LDS update) */
         for (int u = v; u != 255; u = t.parent[u]) { t.n[u] += 1.; t.q[u] += r; }
@@ -596,16 +728,17 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
             if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
         }
         best = lane_bcast(best, 0);
+        MctsParamsK& pe = mcts_params();
         if (lane == 0) {
             const int k = nc > 0 ? t.act[t.child[0][best]] : 4;
-            p.actions_out[2 * (size_t)root] = k / 3;
-            p.actions_out[2 * (size_t)root + 1] = k % 3;
+            pe.actions_out[2 * (size_t)root] = k / 3;
+            pe.actions_out[2 * (size_t)root + 1] = k % 3;
         }
         if (lane < 9) {
             const bool has = lane < nc;
             const int c = has ? t.child[0][lane] : 0;
-            if (p.child_q_out) p.child_q_out[9 * (size_t)root + lane] = has ? t.q[c] : 0.0;
-            if (p.child_n_out) p.child_n_out[9 * (size_t)root + lane] = has ? t.n[c] : 0.0;
+            if (pe.child_q_out) pe.child_q_out[9 * (size_t)root + lane] = has ? t.q[c] : 0.0;
+            if (pe.child_n_out) pe.child_n_out[9 * (size_t)root + lane] = has ? t.n[c] : 0.0;
         }
     }
 }
@@ -614,29 +747,31 @@ __device__ __forceinline__ void mcts_search(const UamMctsParams& p, MctsTree<CAP
  * residency matters more than spill-free registers: with a 128-node tree (simulations <= 126, the shipped 100)
  * and one intruder per lane the LDS footprint allows 4 waves/SIMD, and capping the registers there (128 VGPRs,
  * 68 B of scratch) measures 8 % faster than 3 waves at 147 VGPRs; 5 waves (96 VGPRs, 196 B scratch) is slower. */
-template <int K, int MODEL>
+/* (The kernels read their parameter block through mcts_params(), never through `p`.) */
+template <int K, int MODEL, bool PN>
 __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree<UAM_MCTS_MAX_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
-    mcts_search<K, MODEL, UAM_MCTS_MAX_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
+    mcts_search<K, MODEL, PN, UAM_MCTS_MAX_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
 }
 
-template <int MODEL>
+template <int MODEL, bool PN>
 __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 uam_mcts_search_small_kernel(const UamMctsParams p)
 {
     __shared__ MctsTree<UAM_MCTS_SMALL_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(1)];
     __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
-    mcts_search<1, MODEL, UAM_MCTS_SMALL_NODES>(p, trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
+    mcts_search<1, MODEL, PN, UAM_MCTS_SMALL_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
 }
 
 /* one move() per state, no tree: parity / building block */
-template <int K, int MODEL>
-__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_kernel(const UamMctsParams p)
+template <int K, int MODEL, bool PN>
+__global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_kernel(const UamMctsParams p_)
 {
+    MctsParamsK& p = mcts_params();
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
@@ -652,7 +787,7 @@ __global__ void __launch_bounds__(64 * UAM_MCTS_WAVES_PER_BLOCK) uam_mcts_move_k
     __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
     MctsNoise nz;
     nz.tab = noise[wv]; nz.sim0 = 0; nz.nsim = 0; nz.mv0 = 0; nz.nmv = 1; nz.per_move = true;
-    const uint32_t flags = mcts_move<K, MODEL>(p, rng, lane, sp, gx, gy, a0, a1, s, queues[wv], nz);
+    const uint32_t flags = mcts_move<K, MODEL, PN>(rng, lane, sp, gx, gy, a0, a1, s, queues[wv], nz);
     double* out = p.next_out + (size_t)root * len;
 #pragma unroll
     for (int k = 0; k < K; k++) {

@@ -1,7 +1,8 @@
 /*
  * uam_pmath_impl.h — bodies of the portable fp64 sincos / log (see uam_pmath.h).  Included once per
  * flavour with UAM_PM_NAME (function-name decoration) and UAM_KC (how a polynomial coefficient is
- * materialised) defined by the includer.  No include guard on purpose.
+ * materialised) defined by the includer, and UAM_FMAK(a, z, c) = fma(a, z, coefficient c) (a Horner step).  No include
+ * guard on purpose.
  */
 /* sin and cos of x (|x| < ~1e6 for full accuracy).
  * Reduction: k = rint(x*2/pi), y = x - k*(C1+C2+C3) carried as y0+y1 with
@@ -30,28 +31,28 @@ UAM_HD void UAM_PM_NAME(uam_sincos)(double x, double* sn, double* cs)
     double z = y0 * y0;
     /* sin kernel */
     double ps = UAM_KC(0x1.71b8ef6dcf572p-66);
-    ps = uam_fma(ps, z, UAM_KC(-0x1.2f49b46814157p-57));
-    ps = uam_fma(ps, z, UAM_KC(0x1.952c77030ad4ap-49));
-    ps = uam_fma(ps, z, UAM_KC(-0x1.ae7f3e733b81fp-41));
-    ps = uam_fma(ps, z, UAM_KC(0x1.6124613a86d09p-33));
-    ps = uam_fma(ps, z, UAM_KC(-0x1.ae64567f544e4p-26));
-    ps = uam_fma(ps, z, UAM_KC(0x1.71de3a556c734p-19));
-    ps = uam_fma(ps, z, UAM_KC(-0x1.a01a01a01a01ap-13));
-    ps = uam_fma(ps, z, UAM_KC(0x1.1111111111111p-7));   /* ps = S5 + S7 z + ... */
+    ps = UAM_FMAK(ps, z, -0x1.2f49b46814157p-57);
+    ps = UAM_FMAK(ps, z, 0x1.952c77030ad4ap-49);
+    ps = UAM_FMAK(ps, z, -0x1.ae7f3e733b81fp-41);
+    ps = UAM_FMAK(ps, z, 0x1.6124613a86d09p-33);
+    ps = UAM_FMAK(ps, z, -0x1.ae64567f544e4p-26);
+    ps = UAM_FMAK(ps, z, 0x1.71de3a556c734p-19);
+    ps = UAM_FMAK(ps, z, -0x1.a01a01a01a01ap-13);
+    ps = UAM_FMAK(ps, z, 0x1.1111111111111p-7);   /* ps = S5 + S7 z + ... */
     double v = z * y0;
     /* sin(y0+y1) = y0 + (v*(S3 + z*ps) + y1*(1 - z/2)) */
     double S = y0 + (uam_fma(v, uam_fma(z, ps, UAM_KC(-0x1.5555555555555p-3)), 0.0) + y1 * (1.0 - 0.5 * z));
     /* cos kernel */
     double pc = UAM_KC(-0x1.0ce396db7f853p-70);
-    pc = uam_fma(pc, z, UAM_KC(0x1.e542ba4020225p-62));
-    pc = uam_fma(pc, z, UAM_KC(-0x1.6827863b97d97p-53));
-    pc = uam_fma(pc, z, UAM_KC(0x1.ae7f3e733b81fp-45));
-    pc = uam_fma(pc, z, UAM_KC(-0x1.93974a8c07c9dp-37));
-    pc = uam_fma(pc, z, UAM_KC(0x1.1eed8eff8d898p-29));
-    pc = uam_fma(pc, z, UAM_KC(-0x1.27e4fb7789f5cp-22));
-    pc = uam_fma(pc, z, UAM_KC(0x1.a01a01a01a01ap-16));
-    pc = uam_fma(pc, z, UAM_KC(-0x1.6c16c16c16c17p-10));
-    pc = uam_fma(pc, z, UAM_KC(0x1.5555555555555p-5));   /* pc = C4 + C6 z + ... */
+    pc = UAM_FMAK(pc, z, 0x1.e542ba4020225p-62);
+    pc = UAM_FMAK(pc, z, -0x1.6827863b97d97p-53);
+    pc = UAM_FMAK(pc, z, 0x1.ae7f3e733b81fp-45);
+    pc = UAM_FMAK(pc, z, -0x1.93974a8c07c9dp-37);
+    pc = UAM_FMAK(pc, z, 0x1.1eed8eff8d898p-29);
+    pc = UAM_FMAK(pc, z, -0x1.27e4fb7789f5cp-22);
+    pc = UAM_FMAK(pc, z, 0x1.a01a01a01a01ap-16);
+    pc = UAM_FMAK(pc, z, -0x1.6c16c16c16c17p-10);
+    pc = UAM_FMAK(pc, z, 0x1.5555555555555p-5);   /* pc = C4 + C6 z + ... */
     double hz = 0.5 * z;
     double w = 1.0 - hz;
     double C = w + (((1.0 - w) - hz) + (z * (z * pc) - y0 * y1));
@@ -79,17 +80,17 @@ UAM_HD double UAM_PM_NAME(uam_log)(double x)
     double z = s * s;
     /* log(m) = 2s + s*z*(2/3 + 2/5 z + ...) */
     double r = UAM_KC(0x1.47ae147ae147bp-4);
-    r = uam_fma(r, z, UAM_KC(0x1.642c8590b2164p-4));
-    r = uam_fma(r, z, UAM_KC(0x1.8618618618618p-4));
-    r = uam_fma(r, z, UAM_KC(0x1.af286bca1af28p-4));
-    r = uam_fma(r, z, UAM_KC(0x1.e1e1e1e1e1e1ep-4));
-    r = uam_fma(r, z, UAM_KC(0x1.1111111111111p-3));
-    r = uam_fma(r, z, UAM_KC(0x1.3b13b13b13b14p-3));
-    r = uam_fma(r, z, UAM_KC(0x1.745d1745d1746p-3));
-    r = uam_fma(r, z, UAM_KC(0x1.c71c71c71c71cp-3));
-    r = uam_fma(r, z, UAM_KC(0x1.2492492492492p-2));
-    r = uam_fma(r, z, UAM_KC(0x1.999999999999ap-2));
-    r = uam_fma(r, z, UAM_KC(0x1.5555555555555p-1));
+    r = UAM_FMAK(r, z, 0x1.642c8590b2164p-4);
+    r = UAM_FMAK(r, z, 0x1.8618618618618p-4);
+    r = UAM_FMAK(r, z, 0x1.af286bca1af28p-4);
+    r = UAM_FMAK(r, z, 0x1.e1e1e1e1e1e1ep-4);
+    r = UAM_FMAK(r, z, 0x1.1111111111111p-3);
+    r = UAM_FMAK(r, z, 0x1.3b13b13b13b14p-3);
+    r = UAM_FMAK(r, z, 0x1.745d1745d1746p-3);
+    r = UAM_FMAK(r, z, 0x1.c71c71c71c71cp-3);
+    r = UAM_FMAK(r, z, 0x1.2492492492492p-2);
+    r = UAM_FMAK(r, z, 0x1.999999999999ap-2);
+    r = UAM_FMAK(r, z, 0x1.5555555555555p-1);
     /* f - s*(f - z*r): fdlibm form, exact-ish head f */
     double hfsq = 0.5 * f * f;
     double ke = (double)e;

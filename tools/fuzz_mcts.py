@@ -16,7 +16,7 @@ while time.time() - t0 < budget:
     N = int(rs.choice([1, 2, 3, 8, 20, 63, 64, 65, 100, 129, 200]))
     sims = int(rs.choice([1, 5, 30, 100, 126, 127, 200, 254]))
     depth = int(rs.randint(1, 6))
-    frames = int(rs.choice([1, 3, 10, 16, 33]))
+    frames = int(rs.choice([1, 3, 10, 16, 33, 63]))
     over = dict(simulations=sims, search_depth=depth, simulate_frame=frames, model=model,
                 position_sigma=float(rs.choice([0.0, 0.3])), speed_sigma=float(rs.choice([0.0, 0.07])),
                 heading_change_prob=float(rs.choice([0.0, 0.1, 0.5, 1.0])))
