@@ -327,7 +327,7 @@ typedef struct uam_mcts_config {
     int32_t  num_intruders;      /* N, 1..256 */
     int32_t  simulations;        /* Config.no_simulation = 100   config_single.py:60; 1..254 */
     int32_t  search_depth;       /* Config.search_depth  = 3     config_single.py:61; 1..14 */
-    int32_t  simulate_frame;     /* Config.simulate_frame = 10   config_single.py:59 */
+    int32_t  simulate_frame;     /* Config.simulate_frame = 10   config_single.py:59; 1..63 (one lane per frame) */
     int32_t  model;              /* UAM_MCTS_MODEL_*: which SingleAircraftState.move is restated */
     uint64_t seed;
     double window_width, window_height, minimum_separation;                 /* config_single.py:6-7,16 */

@@ -80,8 +80,40 @@ def test_bad_mcts_config_is_rejected(uamenv):
         uamenv.BatchedMCTS(300).best_action(np.zeros((1, 6 * 300 + 8)))
     with pytest.raises(uamenv.UamError):      # the reference raises too: np.argmax([]) on a terminal root
         uamenv.BatchedMCTS(8, search_depth=0).best_action(np.zeros((1, 56)))
+    with pytest.raises(uamenv.UamError):      # one lane per frame of a move plus one for the state before it
+        uamenv.BatchedMCTS(8, simulate_frame=64).best_action(np.zeros((1, 56)))
     with pytest.raises(ValueError):
         uamenv.BatchedMCTS(8).best_action(np.zeros((1, 40)))
+
+
+def test_long_moves_and_overflowing_change_queue(uamenv, oracle):
+    """63 frames per move (the lane-walked recurrences at their limit) and a heading-change rate that overflows the
+    change queue (more than 128 changes in a move: the slow frame loop), both against the oracle."""
+    rs = np.random.RandomState(21)
+    for N, over in ((20, dict(simulate_frame=63, simulations=20, search_depth=2)),
+                    (64, dict(heading_change_prob=0.5, simulations=30, search_depth=2)),
+                    (40, dict(heading_change_prob=1.0, simulate_frame=16, simulations=12, search_depth=3, speed_sigma=0.07))):
+        B = 3
+        roots = np.zeros((B, 6 * N + 8))
+        for b in range(B):
+            hd = rs.uniform(0, 2 * np.pi, N)
+            sp = rs.uniform(5 / 3, 8 / 3, N)
+            it = np.stack([rs.uniform(0, 800, N), rs.uniform(0, 800, N), sp * np.cos(hd), sp * np.sin(hd), sp, hd], axis=1)
+            roots[b, :6 * N] = it.ravel()
+            roots[b, 6 * N:] = [400, 400, 1.2, 1.2, 1.7, np.pi / 4, rs.uniform(0, 800), rs.uniform(0, 800)]
+        planner = uamenv.BatchedMCTS(N, seed=17, **over)
+        ocfg = _ocfg(oracle, planner.cfg)
+        acts, cq, cn = planner.best_action(roots, root_id0=5, want_children=True)
+        for k in range(B):
+            o = oracle.mcts_best_action(ocfg, roots[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE, root_id=5 + k)
+            assert np.array_equal(cq[k].cpu().numpy(), o["child_q"]) and np.array_equal(cn[k].cpu().numpy(), o["child_n"])
+            assert np.array_equal(acts[k].cpu().numpy(), o["best_action"])
+        a = rs.randint(0, 3, size=(B, 2)).astype(np.int32)
+        nxt, fl, rw = planner.move(roots, a, root_id0=5, sim=2, move=1)
+        for k in range(B):
+            on, of, orw, _ = oracle.mcts_move(ocfg, roots[k], a[k], rng_mode=oracle.RNG_PHILOX, math_impl=oracle.MATH_PORTABLE,
+                                             root_id=5 + k, sim=2, move=1)
+            assert np.array_equal(nxt[k].cpu().numpy(), on) and np.array_equal(fl[k].cpu().numpy(), of) and rw[k].item() == orw
 
 
 def test_many_intruders_and_batch_invariance(uamenv, oracle):
