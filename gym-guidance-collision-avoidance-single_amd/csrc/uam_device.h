@@ -1389,31 +1389,33 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
  * outstanding stores included — and unrolled fp64 slot code is 20 KB of instruction-cache misses for a path that one
  * wave in a few hundred runs. */
 #define UAM_MT_BIG 224
-#define UAM_MT_SLOT_BYTES 40      /* x, y, speed, heading (float64), vx, vy (float32) of one new intruder */
+#define UAM_MT_SLOT_BYTES 48      /* x, y, speed, heading (float64), vx, vy (float32), promoted (uint32) of one new intruder */
 typedef __attribute__((address_space(3))) double* UAM_LDS_F64W;
 typedef __attribute__((address_space(3))) float* UAM_LDS_F32W;
+typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32P;
 
-/* one lane's quad (slots j0 .. 3 of intruders 4 gl .. 4 gl + 3, then the goal if this is the last quad) drawn from
- * the words at buf[off ...).  resume: slot j0 continues INSIDE its rejection loop (its first 8 words were taken by an
- * earlier segment).  Returns words used | ovf << 16 | stop slot << 20 | stopped-in-rejection-loop << 24.
- * COMMIT: keep the results (slot records in LDS, promotion flags, the goal); otherwise only count.
+/* one WORKER lane's intruders (slots j0 .. S - 1 of intruders S v .. S v + S - 1, then the goal if this is the last
+ * worker) drawn from the words at buf[off ...).  resume: slot j0 continues INSIDE its rejection loop (its first 8 words
+ * were taken by an earlier segment).  Returns words used | ovf << 16 | stop slot << 20 | stopped-in-rejection-loop << 24
+ * (stop slot S = stopped at the goal).  COMMIT: keep the results (slot records in LDS, the goal); otherwise only count.
  * The arithmetic is spawn_draw's and spawn_velocity's. */
 template <bool POS64, bool KC>
-__device__ __forceinline__ int mt_quad_from_buffer(const UamParams& p, const UAM_LDS_U32 buf, const int blen, const int off,
-                                                   const int gl, const int Q, const float oxf, const float oyf, const int j0,
-                                                   const bool resume, const bool COMMIT, UAM_LDS_F64W slots, uint32_t& promm,
-                                                   double& gx, double& gy)
+__device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UAM_LDS_U32 buf, const int blen, const int off,
+                                                    const int v, const int S, const bool has_goal, const float oxf, const float oyf,
+                                                    const int j0, const bool resume, const bool COMMIT, UAM_LDS_F64W recs,
+                                                    double& gx, double& gy)
 {
     typedef typename PosT<POS64>::type P;
     typedef Rng<UAM_RNG_MT19937> R;
     int w = 0, jstop = 0;
     bool ovf = false, stop_redraw = false;
 #pragma unroll 1
-    for (int j = j0; j < 4; j++) {
-        if (4 * gl + j < p.N && !ovf) {
+    for (int j = j0; j < S; j++) {
+        const int i = S * v + j;
+        if (i < p.N && !ovf) {
             P x = (P)0, y = (P)0;
             bool prom = false, again = true;
-            const UAM_LDS_F64W rec = slots + 5 * j;
+            const UAM_LDS_F64W rec = recs + 6 * i;
             if (!(resume && j == j0)) {
                 const int o = off + w;
                 if (o + 8 > blen) { ovf = true; jstop = j; stop_redraw = false; }
@@ -1446,14 +1448,14 @@ __device__ __forceinline__ int mt_quad_from_buffer(const UamParams& p, const UAM
                     again = too_close<POS64>(oxf, oyf, x, y, prom, p);
                 }
                 if (!ovf) {
-                    if (COMMIT) { rec[0] = (double)x; rec[1] = (double)y; promm |= (prom ? 1u : 0u) << (4 + j); }
+                    if (COMMIT) { rec[0] = (double)x; rec[1] = (double)y; ((UAM_LDS_U32P)(rec + 5))[0] = prom ? 1u : 0u; }
                 }
             }
         }
     }
-    if (gl == Q - 1 && !ovf) {          /* Goal(position=random_pos()), :91 */
+    if (has_goal && !ovf) {             /* Goal(position=random_pos()), :91 */
         const int o = off + w;
-        if (o + 4 > blen) { ovf = true; jstop = 4; stop_redraw = false; }
+        if (o + 4 > blen) { ovf = true; jstop = S; stop_redraw = false; }
         else {
             w += 4;
             if (COMMIT) {
@@ -1466,7 +1468,13 @@ __device__ __forceinline__ int mt_quad_from_buffer(const UamParams& p, const UAM
 }
 
 /* m = the group's stream (every lane of a group holds its own env's); lds = this wave's reset area:
- * UAM_MT_BIG words, then 4 slot records for each lane of a group */
+ * UAM_MT_BIG words, then one slot record per intruder of an env (4 L of them).
+ * THE WHOLE WAVE WORKS ON THE ONE ENV BEING RESET: worker lane v draws intruders S v .. S v + S - 1 with
+ * S = ceil(N / 64) — ONE intruder per lane up to N = 64 — whichever env's lane group the lane belongs to, and the
+ * env's own lanes pick their quads up from the slot records afterwards.  (Round 2 had the env's L = N / 4 lanes draw four
+ * intruders each, one after the other: a lone wave's chain of dependent fp64 operations, ~44 k cycles of an epilogue
+ * that took ~60 k — not instruction-cache misses: run twice in a row it cost twice, held back until the memory system
+ * was idle it cost the same; profiles/r03_mt_mode.md.) */
 template <bool POS64, bool SH, bool ROS, bool KC>
 __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool need, const int env, const int gl, const int L,
                                               const bool quad_ok, MtWin& m, Quad<POS64, SH>& q, float* tail, float& rox,
@@ -1481,8 +1489,10 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
     typedef typename PosT<POS64>::type P;
     const int lane = threadIdx.x & 63;
     const UAM_LDS_U32 big = (UAM_LDS_U32)lds;
-    const UAM_LDS_F64W slots = (UAM_LDS_F64W)(lds + UAM_MT_BIG) + 20 * gl;
-    const int Q = max(p.Q, 1);       /* (an env without intruders — the packaged copy's default — still draws its goal: lane 0's) */
+    const UAM_LDS_F64W recs = (UAM_LDS_F64W)(lds + UAM_MT_BIG);
+    const int S = max((p.N + 63) >> 6, 1);            /* intruders per worker lane */
+    const int Wn = max((p.N + S - 1) / S, 1);         /* worker lanes (an env without intruders still draws its goal: worker 0's) */
+    const int v = lane;
     unsigned long long pend = __ballot(need && gl == 0);
     while (pend) {                                   /* wave-uniform: one resetting env at a time */
         const int src = __ffsll((long long)pend) - 1;
@@ -1497,11 +1507,10 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
         double ovx = p.c->own_vx0, ovy = p.c->own_vy0;
         float oxf = (float)ox, oyf = (float)oy;
         bool own_done = !ROS;
-        int l0 = 0;                                  /* first lane (quad) of the group not completely drawn yet */
-        int j0 = 0; bool resume = false;             /* ... and where inside it the drawing resumes (that lane only) */
+        int l0 = 0;                                  /* first worker not completely drawn yet */
+        int j0 = 0; bool resume = false;             /* ... and where inside it the drawing resumes (that worker only) */
         int need_lb = (ROS ? 8 : 0) + 8 * p.N + 4;   /* the rest of this reset consumes at least this many words */
         int gen_next = 0;                            /* words of the NEXT round already twisted by a span that ran over */
-        uint32_t promm = 0;
         double gx = 0.0, gy = 0.0;
         for (;;) {                                   /* segments, wave-uniform */
             if (pos >= UAM_MT_N) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
@@ -1525,7 +1534,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
             const int blen = len1 + len2;
             UAM_RSTAMP(0);
             int consumed = 0, finished = 0;
-            if (mine) {
+            {
                 int o0 = 0;
                 if (ROS && !own_done && blen >= 8) {
                     double u[4];
@@ -1536,71 +1545,73 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
                     own_done = true; o0 = 8;
                 }
                 if (own_done) {
-                    const bool active = gl >= l0 && gl < Q;
-                    const int myj0 = gl == l0 ? j0 : 0;
-                    const bool myresume = gl == l0 && resume;
-                    int myoff = o0 + 32 * max(gl - l0, 0);
+                    const bool active = v >= l0 && v < Wn;
+                    const int myj0 = v == l0 ? j0 : 0;
+                    const bool myresume = v == l0 && resume;
+                    int myoff = o0 + 8 * S * max(v - l0, 0);
                     int r = 0;
                     bool commit = false;
-                    int first = Q;
+                    int first = Wn;
                     for (;;) {
-                        /* counting pass: how many words my quad (and, for the last quad, the goal) takes from myoff;
-                         * the last pass (offsets settled) runs the same code once more, for keeps: lanes [l0, first)
-                         * are complete, lane `first` (its start is exact) keeps what fitted */
-                        const bool doit = active && (!commit || gl <= first);
-                        if (doit) r = mt_quad_from_buffer<POS64, KC>(p, big, blen, myoff, gl, Q, oxf, oyf, myj0, myresume, commit, slots, promm, gx, gy);
+                        /* counting pass: how many words my intruders (and, for the last worker, the goal) take from
+                         * myoff; the last pass (offsets settled) runs the same code once more, for keeps: workers
+                         * [l0, first) are complete, worker `first` (its start is exact) keeps what fitted */
+                        const bool doit = active && (!commit || v <= first);
+                        if (doit) r = mt_slots_from_buffer<POS64, KC>(p, big, blen, myoff, v, S, v == Wn - 1, oxf, oyf, myj0, myresume, commit, recs, gx, gy);
                         if (commit) break;
                         if (!active) r = 0;
                         const int w = r & 0xFFFF;
-                        int inc = w;                 /* exclusive prefix sum of the words used, over the lanes of the group */
-                        for (int d = 1; d < L; d <<= 1) {
-                            const int t = __shfl_up(inc, d, L);
-                            if (gl >= d) inc += t;
+                        int inc = w;                 /* exclusive prefix sum of the words used, over the workers */
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int t = __shfl_up(inc, d, 64);
+                            if (lane >= d) inc += t;
                         }
                         const int newoff = o0 + inc - w;
                         const bool moved = active && newoff != myoff;
                         myoff = newoff;
-                        if (!grp_or(moved ? 1u : 0u, L)) {
-                            const bool ovf = (r >> 16) & 1;
-                            first = (int)grp_min(active && ovf ? (uint32_t)gl : (uint32_t)Q, L);
+                        if (!__any(moved)) {
+                            const unsigned long long om = __ballot(active && ((r >> 16) & 1));
+                            first = om ? (int)__ffsll((long long)om) - 1 : Wn;
                             commit = true;
                         }
                     }
                     UAM_RSTAMP(2);
-                    const int endoff = myoff + (r & 0xFFFF);
-                    consumed = (int)grp_max((active && gl <= first) ? (uint32_t)endoff : (uint32_t)o0, L);
-                    /* the resume point of lane `first`, known to the whole group */
-                    const uint32_t st = grp_max((active && gl == first) ? (uint32_t)(r >> 20) & 0x1Fu : 0u, L);
-                    l0 = first; j0 = (int)(st & 0xFu); resume = (st >> 4) & 1u;
-                    finished = first >= Q ? 1 : 0;
+                    /* the last worker that kept something: offsets grow with the worker index */
+                    const int lastw = min(first, Wn - 1);
+                    consumed = max(__shfl(myoff + (r & 0xFFFF), lastw), o0);
+                    /* the resume point of worker `first`, known to the whole wave */
+                    const int stp = first < Wn ? (__shfl(r, first) >> 20) & 0x1F : 0;
+                    l0 = first; j0 = stp & 0xF; resume = (stp >> 4) & 1;
+                    finished = first >= Wn ? 1 : 0;
                 }
             }
-            consumed = __shfl(consumed, src); finished = __shfl(finished, src);
             pos += consumed;
             need_lb = max(need_lb - consumed, 0);
             if (finished) break;
             if (consumed == 0) need_lb = max(need_lb, len1 + 1);      /* short buffer at the end of a round: run over it */
         }
         if (pos >= UAM_MT_N && gen_next > 0) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
+        /* the goal was drawn by the last worker */
+        gx = __shfl(gx, Wn - 1); gy = __shfl(gy, Wn - 1);
+        UAM_WAVE_LDS_SYNC();                         /* the workers' slot records are visible to the env's lanes */
         if (mine) {
             m.pos = pos; m.gen = gen; m.gen_next = 0; m.win_len = 0; m.win_base = 0;
             /* my quad out of its slot records: compile-time slot indices from here on */
-            UAM_WAVE_LDS_SYNC();
+            uint32_t promm = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (quad_ok && 4u * gl + j < (uint32_t)p.N) {
-                    const UAM_LDS_F64W rec = slots + 5 * j;
+                    const UAM_LDS_F64W rec = recs + 6 * (4 * gl + j);
                     q.x[j] = (P)rec[0]; q.y[j] = (P)rec[1];
                     if (SH) { q.sp[SH ? j : 0] = rec[2]; q.hd[SH ? j : 0] = rec[3]; }
                     q.vx[j] = ((UAM_LDS_F32W)(rec + 4))[0]; q.vy[j] = ((UAM_LDS_F32W)(rec + 4))[1];
+                    promm |= (((UAM_LDS_U32P)(rec + 5))[0] & 1u) << (4 + j);
                 }
             }
             q.flags = promm;                   /* new objects: conflict flags cleared */
-            /* the goal was drawn by the last quad's lane */
-            const int gsrc = (lane - gl) + (Q - 1);
-            gx = __shfl(gx, gsrc); gy = __shfl(gy, gsrc);
             reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy, dry);
         }
+        UAM_WAVE_LDS_RELEASE();                     /* (the next resetting env of this wave reuses the records) */
     }
 }
 
