@@ -769,6 +769,20 @@ __device__ __forceinline__ void grp_reduce_pair(T& k, uint32_t& i, int L, Better
 #undef UAM_PAIR_STEP
 }
 
+/* inclusive prefix sum over the 64 lanes of the wave, six DPP additions (no LDS round trips): Hillis-Steele inside the
+ * rows of 16 (row_shr:1/2/4/8, lanes without a source add 0), then each odd row takes the row before it's total
+ * (row_bcast:15) and the upper half the lower half's (row_bcast:31) */
+__device__ __forceinline__ int wave_scan_add(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 /* The 32-bit integer reductions of the sweep (first NMAC index, packed conflict counts): one DPP-modified VALU instruction
  * per butterfly level, v = op(perm(v), v), instead of the copy + hazard nop + v_mov_dpp + op the compiler emits for the
  * generic form (it does not fold the permutation into the consumer).  s_nop 1: a DPP operand written by the previous VALU
@@ -1561,11 +1575,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
                         if (commit) break;
                         if (!active) r = 0;
                         const int w = r & 0xFFFF;
-                        int inc = w;                 /* exclusive prefix sum of the words used, over the workers */
-                        for (int d = 1; d < 64; d <<= 1) {
-                            const int t = __shfl_up(inc, d, 64);
-                            if (lane >= d) inc += t;
-                        }
+                        const int inc = wave_scan_add(w);    /* inclusive prefix sum of the words used, over the workers */
                         const int newoff = o0 + inc - w;
                         const bool moved = active && newoff != myoff;
                         myoff = newoff;
