@@ -315,9 +315,9 @@ __device__ __forceinline__ void mcts_own_traj(const MctsRng& rng, const int lane
  * every change in place.  Returns the number of changes. */
 #define UAM_MCTS_QCAP(K) (128 * (K))
 
-template <int K>
+template <int K, int PART>        /* PART 1: step (1), needs nothing of the node's state; PART 2: steps (2) and (3) */
 __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const int lane, const double* hd0, double* const qbuf,
-                                                    unsigned long long* chg)
+                                                    unsigned long long* chg, int total_in = 0)
 {
     constexpr int QCAP = UAM_MCTS_QCAP(K);
     double* const qh = qbuf;              /* heading after the change */
@@ -327,8 +327,8 @@ __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const in
     unsigned long long* const tab_m = (unsigned long long*)qc;     /* [F * K] <= 63 K * 8 B */
     int* const tab_b = (int*)(tab_m + 64 * K);                     /* [F * K]: 512 K + 256 K <= 1024 K B */
     uint32_t* const qw = (uint32_t*)qs;                            /* [QCAP] the changes' words */
-    int total = 0;
-    {
+    int total = total_in;
+    if constexpr (PART == 1) {
         MctsParamsK& p = mcts_params();
         const int F = p.frames;
         /* (1) mark the changes, queue their words */
@@ -371,6 +371,7 @@ __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const in
         }
         }
     }
+    if constexpr (PART == 1) return total;
     if (total > QCAP) return total;
     mcts_wave_sync();
     {
@@ -432,6 +433,12 @@ __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int la
     uint32_t flags = 0;
     fe = F - 1;
     int qbase = 0;
+    /* without position noise a frame adds (velocity + 0.0): the same value every frame until the heading changes, so the
+     * sum is formed once per velocity instead of once per frame (same operations on the same values) */
+    double vxz[K], vyz[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { vxz[k] = s.vx[k] + 0.0; vyz[k] = s.vy[k] + 0.0; }
+    (void)vxz; (void)vyz;
     for (int f = 0; f < F; f++) {
         /* ---- intruders: position += velocity (+ noise), Bernoulli heading change, :54-70 */
 #pragma unroll
@@ -448,8 +455,8 @@ __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int la
             /* (slots beyond Nsim hold zeros or, STRAIGHT4's unmoved last intruder, are never read back as moved:
              * they are integrated under the lane mask like the rest) */
             if ((inm[k] >> lane) & 1ull) {
-                s.x[k] += s.vx[k] + nx_;
-                s.y[k] += s.vy[k] + ny_;
+                if constexpr (PN) { s.x[k] += s.vx[k] + nx_; s.y[k] += s.vy[k] + ny_; }
+                else { s.x[k] += vxz[k]; s.y[k] += vyz[k]; }
             }
             if constexpr (!M4) {
                 const bool c = (chg[k] >> f) & 1ull;
@@ -459,6 +466,7 @@ __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int la
                     s.hd[k] = qh[idx];
                     s.vx[k] = sp[k] * qc[idx];
                     s.vy[k] = sp[k] * qs[idx];
+                    if constexpr (!PN) { vxz[k] = s.vx[k] + 0.0; vyz[k] = s.vy[k] + 0.0; }
                 }
                 qbase += __popcll(m);
             }
@@ -532,11 +540,14 @@ __device__ __forceinline__ uint32_t mcts_move(const MctsRng& rng, const int lane
                                               const int a0, const int a1, MctsState<K>& s, double* qbuf, MctsNoise& nz)
 {
     constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
-    MctsOwnTraj o;
-    mcts_own_traj<K, MODEL>(rng, lane, gx, gy, a0, a1, s, nz, o);
+    /* the marks first: they need nothing of the node's state, whose loads (an expansion's parent comes from HBM) are
+     * still in flight when the move starts */
     unsigned long long chg[K];
     int total = 0;
-    if constexpr (!M4) total = mcts_heading_prepass<K>(rng, lane, s.hd, qbuf, chg);
+    if constexpr (!M4) total = mcts_heading_prepass<K, 1>(rng, lane, nullptr, qbuf, chg);
+    MctsOwnTraj o;
+    mcts_own_traj<K, MODEL>(rng, lane, gx, gy, a0, a1, s, nz, o);
+    if constexpr (!M4) total = mcts_heading_prepass<K, 2>(rng, lane, s.hd, qbuf, chg, total);
     uint32_t flags;
     int fe;
     if (M4 || total <= UAM_MCTS_QCAP(K)) flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbuf, fe);
