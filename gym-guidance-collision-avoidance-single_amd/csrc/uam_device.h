@@ -1402,7 +1402,8 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
  * record, was as slow as the serial walk: every call boundary drains the vector-memory counter — the step's
  * outstanding stores included — and unrolled fp64 slot code is 20 KB of instruction-cache misses for a path that one
  * wave in a few hundred runs. */
-#define UAM_MT_BIG 224
+#define UAM_MT_BIG 224            /* words twisted in parallel by one chunk (any <= 227 consecutive words are independent) */
+#define UAM_MT_BUF (2 * UAM_MT_BIG)   /* the reset's word buffer: two chunks, the second behind the first one's stores */
 #define UAM_MT_SLOT_BYTES 48      /* x, y, speed, heading (float64), vx, vy (float32), promoted (uint32) of one new intruder */
 typedef __attribute__((address_space(3))) double* UAM_LDS_F64W;
 typedef __attribute__((address_space(3))) float* UAM_LDS_F32W;
@@ -1503,7 +1504,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
     typedef typename PosT<POS64>::type P;
     const int lane = threadIdx.x & 63;
     const UAM_LDS_U32 big = (UAM_LDS_U32)lds;
-    const UAM_LDS_F64W recs = (UAM_LDS_F64W)(lds + UAM_MT_BIG);
+    const UAM_LDS_F64W recs = (UAM_LDS_F64W)(lds + UAM_MT_BUF);
     const int S = max((p.N + 63) >> 6, 1);            /* intruders per worker lane */
     const int Wn = max((p.N + S - 1) / S, 1);         /* worker lanes (an env without intruders still draws its goal: worker 0's) */
     const int v = lane;
@@ -1528,24 +1529,40 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
         double gx = 0.0, gy = 0.0;
         for (;;) {                                   /* segments, wave-uniform */
             if (pos >= UAM_MT_N) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
-            const int len1 = min(UAM_MT_BIG, UAM_MT_N - pos);
-            /* over the end of the round (see mt_win_refill) when the reset is certain to consume past it */
-            const int len2 = (len1 < UAM_MT_BIG && need_lb > len1) ? UAM_MT_BIG - len1 : 0;
             UAM_WAVE_LDS_RELEASE();                 /* the previous segment's reads of the buffer are done */
+            /* Up to two chunks of UAM_MT_BIG words per segment, the second only when the reset is certain to consume past
+             * the first: a reset of N = 32 takes 260 words and more, so with one chunk it always took two segments — two
+             * rounds of settling passes.  The second chunk's words depend on the first one's (word k on word k - 227 of its
+             * round): its loads are issued behind the first chunk's stores by the same wave, which is all the ordering they
+             * need.  vstart: where the next chunk starts, counted in the round of `pos` (>= 624: in the next round). */
+            int blen = 0, first_len = 0;
+            int vstart = pos;
 #pragma unroll 1
-            for (int part = 0; part < 2; part++) {      /* (one body for both parts: code bytes) */
-                const int plen = part ? len2 : len1;
+            for (int chunk = 0; chunk < 2; chunk++) {
+                if (chunk == 1 && need_lb <= blen) break;
+                const bool nextr = vstart >= UAM_MT_N;               /* the chunk lies in the next round altogether */
+                const int cpos = nextr ? vstart - UAM_MT_N : vstart;
+                const int len1 = min(UAM_MT_BIG, UAM_MT_N - cpos);
+                /* over the end of the round (see mt_win_refill) when the reset is certain to consume past it */
+                const int len2 = (!nextr && len1 < UAM_MT_BIG && need_lb > blen + len1) ? UAM_MT_BIG - len1 : 0;
+#pragma unroll 1
+                for (int part = 0; part < 2; part++) {      /* (one body for both parts: code bytes) */
+                    const int plen = part ? len2 : len1;
+                    const int pgen = (part || nextr) ? gen_next : gen;
 #if UAM_STAMP
-                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), st + 4, dry);
+                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), st + 4, dry);
 #else
-                if (plen > 0) mt_twist_span<4>(key, part ? 0 : pos, part ? gen_next : gen, plen, lane, 64, (UAM_LDS_U32W)lds + (part ? len1 : 0), nullptr, dry);
+                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), nullptr, dry);
 #endif
+                }
+                if (nextr) gen_next = max(gen_next, cpos + len1);
+                else { gen = max(gen, cpos + len1); gen_next = max(gen_next, len2); }
+                if (chunk == 0) first_len = len1;
+                blen += len1 + len2;
+                vstart += len1 + len2;
             }
             UAM_RSTAMP(3);
-            gen = max(gen, pos + len1);
-            gen_next = max(gen_next, len2);
             UAM_WAVE_LDS_SYNC();
-            const int blen = len1 + len2;
             UAM_RSTAMP(0);
             int consumed = 0, finished = 0;
             {
@@ -1598,7 +1615,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
             pos += consumed;
             need_lb = max(need_lb - consumed, 0);
             if (finished) break;
-            if (consumed == 0) need_lb = max(need_lb, len1 + 1);      /* short buffer at the end of a round: run over it */
+            if (consumed == 0) need_lb = max(need_lb, first_len + 1);  /* short buffer at the end of a round: run over it */
         }
         if (pos >= UAM_MT_N && gen_next > 0) { pos -= UAM_MT_N; gen = gen_next; gen_next = 0; }
         /* the goal was drawn by the last worker */
@@ -2127,7 +2144,7 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     const int mt_cap = min(p.mt_win, max(UAM_MT_RU * L, 16));
     /* this wave's reset area (reset_wave_mt): behind the windows, 8-byte aligned */
     uint32_t* const mt_reset_lds = mt_win_base + (((size_t)p.E * p.mt_win + 1) & ~(size_t)1) +
-                                   (size_t)(tid >> 6) * (UAM_MT_BIG + (UAM_MT_SLOT_BYTES / 4) * 4 * L);
+                                   (size_t)(tid >> 6) * (UAM_MT_BUF + (UAM_MT_SLOT_BYTES / 4) * 4 * L);
     if constexpr (PERSIST) {
         if (env_first >= p.B) return;
     } else if constexpr (RNG == UAM_RNG_MT19937) {

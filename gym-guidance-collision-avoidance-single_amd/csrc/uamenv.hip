@@ -644,7 +644,7 @@ static UamSweepFn mt_many_fn(const uam_env* e)
 static inline size_t lds_step(const uam_env* e, bool staged)
 {
     return (staged ? (size_t)e->E * e->D * 4 : 0) + (size_t)e->E * 48 +
-           (e->cfg.rng_mode == UAM_RNG_MT19937 ? (size_t)e->E * 32 + 4 * (((size_t)e->E * e->mt_win + 1) & ~(size_t)1) + (size_t)((e->T + 63) / 64) * (UAM_MT_BIG * 4 + UAM_MT_SLOT_BYTES * 4 * (size_t)e->L) : 0);
+           (e->cfg.rng_mode == UAM_RNG_MT19937 ? (size_t)e->E * 32 + 4 * (((size_t)e->E * e->mt_win + 1) & ~(size_t)1) + (size_t)((e->T + 63) / 64) * (UAM_MT_BUF * 4 + UAM_MT_SLOT_BYTES * 4 * (size_t)e->L) : 0);
 }
 
 /* K steps in one launch (float32 / Philox instances only; everything else loops over single steps) */
