@@ -1418,10 +1418,21 @@ template <bool POS64, bool KC>
 __device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UAM_LDS_U32 buf, const int blen, const int off,
                                                     const int v, const int S, const bool has_goal, const float oxf, const float oyf,
                                                     const int j0, const bool resume, const bool COMMIT, UAM_LDS_F64W recs,
-                                                    double& gx, double& gy)
+                                                    double& gx, double& gy, const double cW, const double cH,
+                                                    const float init2f, const double init2d)
 {
     typedef typename PosT<POS64>::type P;
     typedef Rng<UAM_RNG_MT19937> R;
+    /* too_close with the thresholds the caller read once, ahead of the settling passes (this translation unit is
+     * built without machine LICM: inside the passes every use would be its own scalar load and wait) */
+    auto close_to = [&](P x, P y, bool prom) -> bool {
+        if (POS64 && prom) {
+            const double dx = (double)oxf - (double)x, dy = (double)oyf - (double)y;
+            return uam_fma(dy, dy, dx * dx) < init2d;
+        }
+        const float dx = oxf - (float)x, dy = oyf - (float)y;
+        return dx * dx + dy * dy < init2f;
+    };
     int w = 0, jstop = 0;
     bool ovf = false, stop_redraw = false;
 #pragma unroll 1
@@ -1437,7 +1448,7 @@ __device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UA
                 else {
                     const double u0 = R::dbl(buf[o], buf[o + 1]), u1 = R::dbl(buf[o + 2], buf[o + 3]);
                     w += 8;
-                    const double fx = 0.0 + p.c->W * u0, fy = 0.0 + p.c->H * u1;
+                    const double fx = 0.0 + cW * u0, fy = 0.0 + cH * u1;
                     x = (P)(float)fx; y = (P)(float)fy;
                     if (COMMIT) {
                         const double u2 = R::dbl(buf[o + 4], buf[o + 5]), u3 = R::dbl(buf[o + 6], buf[o + 7]);
@@ -1448,7 +1459,7 @@ __device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UA
                         rec[2] = sp; rec[3] = hd;
                         ((UAM_LDS_F32W)(rec + 4))[0] = vx; ((UAM_LDS_F32W)(rec + 4))[1] = vy;
                     }
-                    again = too_close<POS64>(oxf, oyf, x, y, prom, p);
+                    again = close_to(x, y, prom);
                 }
             }
             if (!ovf) {
@@ -1457,10 +1468,10 @@ __device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UA
                     if (o2 + 4 > blen) { ovf = true; jstop = j; stop_redraw = true; break; }
                     const double r1 = R::dbl(buf[o2], buf[o2 + 1]), r2 = R::dbl(buf[o2 + 2], buf[o2 + 3]);
                     w += 4;
-                    const double fx = 0.0 + p.c->W * r1, fy = 0.0 + p.c->H * r2;
+                    const double fx = 0.0 + cW * r1, fy = 0.0 + cH * r2;
                     if (POS64) { x = (P)fx; y = (P)fy; prom = true; }   /* redraw kept as float64, :86,:237 */
                     else { x = (P)(float)fx; y = (P)(float)fy; }
-                    again = too_close<POS64>(oxf, oyf, x, y, prom, p);
+                    again = close_to(x, y, prom);
                 }
                 if (!ovf) {
                     if (COMMIT) { rec[0] = (double)x; rec[1] = (double)y; ((UAM_LDS_U32P)(rec + 5))[0] = prom ? 1u : 0u; }
@@ -1521,6 +1532,8 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
         double ox = p.c->own_x0, oy = p.c->own_y0, osp = p.c->own_speed0, ohd = p.c->own_heading0;
         double ovx = p.c->own_vx0, ovy = p.c->own_vy0;
         float oxf = (float)ox, oyf = (float)oy;
+        const double cW = p.c->W, cH = p.c->H, init2d = p.c->init2;
+        const float init2f = p.init2_32;
         bool own_done = !ROS;
         int l0 = 0;                                  /* first worker not completely drawn yet */
         int j0 = 0; bool resume = false;             /* ... and where inside it the drawing resumes (that worker only) */
@@ -1588,7 +1601,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
                          * myoff; the last pass (offsets settled) runs the same code once more, for keeps: workers
                          * [l0, first) are complete, worker `first` (its start is exact) keeps what fitted */
                         const bool doit = active && (!commit || v <= first);
-                        if (doit) r = mt_slots_from_buffer<POS64, KC>(p, big, blen, myoff, v, S, v == Wn - 1, oxf, oyf, myj0, myresume, commit, recs, gx, gy);
+                        if (doit) r = mt_slots_from_buffer<POS64, KC>(p, big, blen, myoff, v, S, v == Wn - 1, oxf, oyf, myj0, myresume, commit, recs, gx, gy, cW, cH, init2f, init2d);
                         if (commit) break;
                         if (!active) r = 0;
                         const int w = r & 0xFFFF;
