@@ -347,6 +347,45 @@ def measure(ctx, args, scaling, variant, steps, warmup, reps, want_bracketed, fu
     return out
 
 
+def config5_planner(ctx, reps=5):
+    """BASELINE.json configs[4] beside the headline: the batched MCTS planner (8192 roots x 64 intruders, 100
+    simulations, depth 3) that drives the RandIntruder env — ms per batched plan on this GPU, and the env steps per
+    second of the reference's agent loop (Agent_RandInt.py: a plan every 5th step).  An extra: never `value`."""
+    import time
+    import uamenv
+    torch = ctx.torch
+    B, N = 8192, 64
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=0)
+    env.reset()
+    for _ in range(20):
+        env.step(env.policy_actions("goal"))
+    planner = uamenv.BatchedMCTS(N, seed=0)
+    roots = planner.roots_from_env(env)
+    planner.best_action(roots)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for r in range(reps):
+        acts = planner.best_action(roots, root_id0=(r + 1) * B)
+        ev[r + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
+    steps = 25
+    t0 = time.perf_counter()
+    for t in range(steps):
+        if t % 5 == 0:
+            acts = planner.best_action(planner.roots_from_env(env), root_id0=(reps + 2 + t) * B)
+        env.step(acts)
+    torch.cuda.synchronize()
+    loop_s = time.perf_counter() - t0
+    env.close()
+    return {"workload": "BASELINE.json configs[4]: RandIntruder env 8192 x 64 driven by the batched MCTS planner "
+                        "(100 simulations, depth 3, 10 frames per move), one wavefront per root",
+            "ms_per_batched_plan": ms[len(ms) // 2], "reps_ms": ms, "decisions_per_sec": B / (ms[len(ms) // 2] * 1e-3),
+            "agent_loop_env_steps_per_sec": B * steps / loop_s,
+            "agent_loop": "a plan every 5th env step (Algorithms/MCTS/Agent_RandInt.py), %d steps, host-timed" % steps}
+
+
 def copy_ms(torch, dev, nbytes, iters):
     """Plain device copies that move `nbytes` in total (half read, half written): the practical HBM ceiling.  Two
     kernels: the library's own hand-written copy (uam_bench_copy: one 16-byte element per thread, the float4 copy
@@ -556,6 +595,12 @@ def main():
             resident = hbm_resident(ctx, args, pvar)
         except Exception as ex:       # an extra; must never take the measurement down
             resident = {"error": repr(ex)}
+    planner = None
+    if ctx.world == 1 and not args.no_secondary and args.policy == "random" and args.rng == "philox":
+        try:
+            planner = config5_planner(ctx)
+        except Exception as ex:       # an extra; must never take the measurement down
+            planner = {"error": repr(ex)}
     sustained = None
     if args.sustain_seconds > 0 and args.policy == "random":
         # the closing GPU phase: the primary workload for seconds (the CPU baseline ran first, so the device is busy at
@@ -630,6 +675,8 @@ def main():
                                             "registers for the chunk, so a step moves %d B/env instead of %d"
                                             % (fused["chunk"], fused["launch_bytes"] // (fused["chunk"] * res["envs_per_gpu"]),
                                                res["step_bytes"] // res["envs_per_gpu"]))
+        if planner is not None:
+            out["config5_planner"] = planner
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
