@@ -874,3 +874,88 @@ def test_shared_stream_batch_replays_the_reference_process(uamenv, oracle):
                     check_state_every=10)
     with pytest.raises(uamenv.UamError):
         uamenv.BatchedSingleAircraftEnv(2048, 8, rng="mt19937_shared", precision="exact")
+
+
+def test_benchmarked_instance_spawn_law_matches_the_reference_stream(uamenv):
+    """The benchmarked instance (Philox, float32, the lean spawn: 24-bit uniforms, float32 quadrant sincos) is
+    builder-defined on both sides of its lockstep tests, so here its SPAWN LAW is held against the reference's:
+    analytically (random_pos / random_speed / random_heading and the redraw-while-too-close rule,
+    Simulators/SingleAircraftEnv.py:230-251, 270-279) and empirically, two-sample, against the MT19937 / exact
+    instance, which replays the reference's own stream seed for seed."""
+    from scipy import stats
+    B, N = 8192, 32
+    cfg = uamenv.Config
+    W, H = float(cfg.window_width), float(cfg.window_height)
+
+    def spawn_sample(**kw):
+        env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=123, **kw)
+        env.reset()
+        st = env.get_state(["int_x", "int_y", "int_vx", "int_vy", "int_speed", "int_heading", "own_x", "own_y"])
+        env.close()
+        return {k: np.asarray(v, dtype=np.float64) for k, v in st.items() if k != "step_index"}
+
+    lean = spawn_sample(rng="philox", precision="f32")
+    ref = spawn_sample(rng="mt19937", precision="exact")
+    for s in (lean, ref):
+        x, y = s["int_x"].ravel(), s["int_y"].ravel()
+        ox, oy = np.repeat(s["own_x"], N), np.repeat(s["own_y"], N)
+        # inside the map, never closer to the ownship than initial_min_dist
+        assert x.min() >= 0 and x.max() <= W and y.min() >= 0 and y.max() <= H
+        assert np.hypot(x - ox, y - oy).min() >= cfg.initial_min_dist - 1e-3
+        # speed and heading uniform on their ranges; the velocity is the held speed along the held heading
+        sp, hd = s["int_speed"].ravel(), s["int_heading"].ravel()
+        assert stats.kstest((sp - cfg.min_speed) / (cfg.max_speed - cfg.min_speed), "uniform").pvalue > 1e-3
+        assert stats.kstest(hd / (2 * np.pi), "uniform").pvalue > 1e-3
+        vx, vy = s["int_vx"].ravel(), s["int_vy"].ravel()
+        assert np.abs(vx - sp * np.cos(hd)).max() < 2e-6 and np.abs(vy - sp * np.sin(hd)).max() < 2e-6
+        # positions uniform on the map outside the exclusion disc: away from the disc's bounding box both marginals are
+        far = (x > ox + cfg.initial_min_dist) & (y > oy + cfg.initial_min_dist)
+        lo_x, lo_y = (ox + cfg.initial_min_dist)[far], (oy + cfg.initial_min_dist)[far]
+        assert stats.kstest((x[far] - lo_x) / (W - lo_x), "uniform").pvalue > 1e-3
+        assert stats.kstest((y[far] - lo_y) / (H - lo_y), "uniform").pvalue > 1e-3
+    # and the two instances draw from the same law
+    for k in ("int_x", "int_y", "int_speed", "int_heading", "int_vx", "int_vy"):
+        assert stats.ks_2samp(lean[k].ravel(), ref[k].ravel()).pvalue > 1e-3, k
+    # the fraction of spawns that needed a redraw is the disc's share of the map in both
+    # (not observable from the state; the promoted-position flag of the exact instance is its trace)
+
+
+def test_benchmarked_instance_heading_change_law_matches_the_reference_stream(uamenv):
+    """RandIntruder's _update_headings (SingleAircraftMCTSRandIntruderEnv.py:166-174, 332-336) on the benchmarked
+    instance — one Philox block per quad, a change's second uniform taken as u / p — against its law (each intruder
+    changes with probability heading_change_prob per step, by a uniform angle within +-heading_change_max_deg) and,
+    two-sample, against the MT19937 / exact instance that replays the reference's stream."""
+    from scipy import stats
+    import torch
+    B, N, T = 2048, 32, 12
+    prob, max_deg = 0.1, 10.0          # Simulators/config.py: the RandIntruder env's constants (uam_config defaults)
+
+    def deltas(**kw):
+        env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=77, **kw)
+        assert abs(env.cfg.heading_change_prob - prob) < 1e-12 and abs(env.cfg.heading_change_max_deg - max_deg) < 1e-12
+        env.reset()
+        fields = ["int_x", "int_y", "int_heading"]
+        prev = env.get_state(fields)
+        changed, total, dd = 0, 0, []
+        for t in range(T):
+            env.step(env.policy_actions("goal", seed=t + 1))
+            cur = env.get_state(fields)
+            # intruders that were neither respawned nor reset in this step moved by their velocity (< 3 per step)
+            cont = np.hypot(cur["int_x"].astype(np.float64) - prev["int_x"], cur["int_y"].astype(np.float64) - prev["int_y"]) < 4.0
+            dh = (cur["int_heading"] - prev["int_heading"])[cont]
+            total += dh.size
+            changed += int((dh != 0).sum())
+            dd.append(dh[dh != 0])
+            prev = cur
+        env.close()
+        return changed, total, np.degrees(np.concatenate(dd))
+
+    out = {}
+    for name, kw in (("lean", dict(rng="philox", precision="f32")), ("ref", dict(rng="mt19937", precision="exact"))):
+        changed, total, dd = deltas(**kw)
+        rate = changed / total
+        assert abs(rate - prob) < 5 * np.sqrt(prob * (1 - prob) / total), (name, rate)
+        assert np.abs(dd).max() <= max_deg + 1e-9
+        assert stats.kstest((dd + max_deg) / (2 * max_deg), "uniform").pvalue > 1e-3, name
+        out[name] = dd
+    assert stats.ks_2samp(out["lean"], out["ref"]).pvalue > 1e-3
