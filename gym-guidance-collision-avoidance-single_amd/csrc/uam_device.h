@@ -2670,8 +2670,12 @@ uam_sweep_mt_many_kernel(const UamParams p)
         /* every step reads its parameters afresh from the kernarg segment (scalar loads, cached): with the by-value copy
          * the compiler hoists what it derives from them — array bases, env offsets, fp64 literals — out of the K loop
          * and keeps it all in registers across the step (255 VGPRs without spilling, 568 B of scratch at 128) */
-        const UamParams* pp = (const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(pp) :: "memory");
+        /* (the pointer is made opaque IN the constant address space and cast afterwards: the loads through it are
+         * then scalar loads into SGPRs; laundered as a generic pointer they were FLAT loads of wave-uniform values into
+         * VGPRs, a vector-memory round trip at the head of every step) */
+        const __attribute__((address_space(4))) UamParams* pp4 = (const __attribute__((address_space(4))) UamParams*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pp4) :: "memory");
+        const UamParams* pp = (const UamParams*)pp4;
         sweep_step<POS64, UAM_RNG_MT19937, MODE, SH, ROS, false, false>(*pp, lds_raw, k, obs_k, q, vd, ncf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2700,8 +2704,9 @@ uam_sweep_heavy_many_kernel(const UamParams p)
         Quad<POS64, SH> q;
         bool vd = false;
         int32_t ncf = 0;
-        const UamParams* pp = (const UamParams*)__builtin_amdgcn_kernarg_segment_ptr();      /* (see uam_sweep_mt_many_kernel) */
-        asm volatile("" : "+s"(pp) :: "memory");
+        const __attribute__((address_space(4))) UamParams* pp4 = (const __attribute__((address_space(4))) UamParams*)__builtin_amdgcn_kernarg_segment_ptr();      /* (see uam_sweep_mt_many_kernel) */
+        asm volatile("" : "+s"(pp4) :: "memory");
+        const UamParams* pp = (const UamParams*)pp4;
         sweep_step<POS64, RNG, MODE, SH, ROS, (POS64 && !SH && RNG == UAM_RNG_PHILOX), false>(*pp, lds_raw, k, obs_k, q, vd, ncf);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
