@@ -355,11 +355,23 @@ def config5_planner(ctx, reps=5):
     import uamenv
     torch = ctx.torch
     B, N = 8192, 64
-    env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=0)
+    out = {}
+    for key, variant, model, what in (
+            ("agent_randint", "randintruder", "randintru", "RandIntruder env + nodes_single_randintru.py (Algorithms/MCTS/Agent_RandInt.py)"),
+            ("agent", "mcts", "straight4", "SingleAircraftMCTSEnv + nodes_single.py, upstream quirks included (Algorithms/MCTS/Agent.py)")):
+        out[key] = _planner_run(torch, uamenv, B, N, variant, model, what, reps)
+    out["workload"] = ("BASELINE.json configs[4]: batch 8192 x 64 intruders driven by the batched MCTS planner (100 simulations, "
+                       "depth 3, 10 frames per move), one wavefront per root; both of the reference's agent pairings")
+    return out
+
+
+def _planner_run(torch, uamenv, B, N, variant, model, what, reps):
+    import time
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=0)
     env.reset()
     for _ in range(20):
         env.step(env.policy_actions("goal"))
-    planner = uamenv.BatchedMCTS(N, seed=0)
+    planner = uamenv.BatchedMCTS(N, seed=0, model=model)
     roots = planner.roots_from_env(env)
     planner.best_action(roots)
     torch.cuda.synchronize()
@@ -379,11 +391,10 @@ def config5_planner(ctx, reps=5):
     torch.cuda.synchronize()
     loop_s = time.perf_counter() - t0
     env.close()
-    return {"workload": "BASELINE.json configs[4]: RandIntruder env 8192 x 64 driven by the batched MCTS planner "
-                        "(100 simulations, depth 3, 10 frames per move), one wavefront per root",
+    return {"pairing": what,
             "ms_per_batched_plan": ms[len(ms) // 2], "reps_ms": ms, "decisions_per_sec": B / (ms[len(ms) // 2] * 1e-3),
             "agent_loop_env_steps_per_sec": B * steps / loop_s,
-            "agent_loop": "a plan every 5th env step (Algorithms/MCTS/Agent_RandInt.py), %d steps, host-timed" % steps}
+            "agent_loop": "a plan every 5th env step (the loop of Agent.py / Agent_RandInt.py), %d steps, host-timed" % steps}
 
 
 def copy_ms(torch, dev, nbytes, iters):

@@ -15,14 +15,16 @@ ap.add_argument("--sims", type=int, default=100)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--cpu-roots", type=int, default=16)
+ap.add_argument("--model", default="randintru", choices=["randintru", "straight4"],
+                help="randintru: nodes_single_randintru.py on the RandIntruder env (Agent_RandInt.py); straight4: nodes_single.py on SingleAircraftMCTSEnv (Agent.py)")
 args = ap.parse_args()
 
 B, N = args.batch, args.intruders
-env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder", seed=0)
+env = uamenv.BatchedSingleAircraftEnv(B, N, variant="randintruder" if args.model == "randintru" else "mcts", seed=0)
 env.reset()
 for _ in range(20):
     env.step(env.policy_actions("goal"))
-planner = uamenv.BatchedMCTS(N, seed=0, simulations=args.sims, search_depth=args.depth)
+planner = uamenv.BatchedMCTS(N, seed=0, simulations=args.sims, search_depth=args.depth, model=args.model)
 roots = planner.roots_from_env(env)
 planner.best_action(roots)
 torch.cuda.synchronize()
@@ -42,7 +44,7 @@ for t in range(steps):
     env.step(acts)
 torch.cuda.synchronize()
 loop_s = time.perf_counter() - t0
-out = {"batch": B, "intruders": N, "sims": args.sims, "depth": args.depth,
+out = {"batch": B, "intruders": N, "sims": args.sims, "depth": args.depth, "model": args.model,
        "gpu_ms_per_batched_decision": gpu_s * 1e3, "gpu_decisions_per_s": B / gpu_s,
        "agent_loop_env_steps_per_s": B * steps / loop_s}
 try:
