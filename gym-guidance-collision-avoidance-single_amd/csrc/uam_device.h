@@ -1759,6 +1759,9 @@ __device__ __forceinline__ void own_fetch_inputs(const UamParams& p, const int e
 
 /* out of line for the looped kernel: inlined, the policy's fp64 atan2 and Philox rounds put 26 more VGPRs on every lane
  * of the kernel (108 -> 134, one wave per SIMD less) although only its ownship wave ever runs them */
+/* (The pointer argument arrives in vector registers, so the function's five parameter reads are flat loads.  Reading the
+ * kernarg segment INSIDE the function instead is not an option: in a callable function the compiler folds
+ * __builtin_amdgcn_kernarg_segment_ptr() to a null pointer — tried in round 3, a memory fault on the first call.) */
 __device__ __attribute__((noinline)) uint2 uam_policy_eval_fn(const UamParams* p, int kind, int e, float ox, float oy, double hd,
                                                               double gx, double gy, uint32_t call)
 {
