@@ -39,6 +39,9 @@
 #ifndef UAM_ABLATE
 #define UAM_ABLATE 0   /* development-only ablation mask (tools/ablate.py); 0 in every shipped build */
 #endif
+#ifndef UAM_HEAVY_MANY_WAVES
+#define UAM_HEAVY_MANY_WAVES 4      /* waves per SIMD the float64-position Philox K-step kernel is held to: 4 measures 18.85 us per step at 65536x32, 5 (more spills) and 3 (no spills) 20.2-20.3 */
+#endif
 #ifndef UAM_PHILOX_WIDE
 #define UAM_PHILOX_WIDE 0   /* 1: 64-bit products in Philox (fewer quarter-rate multiplies, more VGPRs: 63 -> 71 in the step kernel) */
 #endif
@@ -2690,7 +2693,7 @@ uam_sweep_mt_many_kernel(const UamParams p)
  * block barrier between steps (the ownship records in LDS are the block's) — without the per-launch ramp and tail
  * (a step launch is its slowest wave).  The float32 instances have the register-resident looped kernel. */
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS>
-__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__(UAM_MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(UAM_HEAVY_MANY_WAVES, 8)))
 uam_sweep_heavy_many_kernel(const UamParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
