@@ -263,6 +263,7 @@ __device__ __forceinline__ void mcts_own_traj(const MctsRng& rng, const int lane
          * (state[-5], :60 — `accel` is dead), which chains through sin(heading): the walked value is vy */
         (void)accel;
         double hdg = s.ohd;
+        UAM_MCTS_REPEAT(8)
 #pragma unroll 1
         for (int t = 0; t < F; t++) {
             double h = dpp_mov<UAM_DPP_WAVE_SHR1>(hdg);
@@ -272,9 +273,13 @@ __device__ __forceinline__ void mcts_own_traj(const MctsRng& rng, const int lane
         }
         o.hd = hdg;
         double sn, cs;
-        uam_sincos_k(o.hd, &sn, &cs);
+        UAM_MCTS_REPEAT(16) {
+            if (rep_) asm volatile("" : "+v"(o.hd));
+            uam_sincos_k(o.hd, &sn, &cs);
+        }
         const double sn_l = lane == 0 ? 1.0 : sn;
         double vy = s.ovy, spd = 0.0;
+        UAM_MCTS_REPEAT(8)
 #pragma unroll 1
         for (int t = 0; t < F; t++) {
             double v = dpp_mov<UAM_DPP_WAVE_SHR1>(vy);
@@ -550,7 +555,17 @@ __device__ __forceinline__ uint32_t mcts_move(const MctsRng& rng, const int lane
     if constexpr (!M4) total = mcts_heading_prepass<K, 2>(rng, lane, s.hd, qbuf, chg, total);
     uint32_t flags;
     int fe;
-    if (M4 || total <= UAM_MCTS_QCAP(K)) flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbuf, fe);
+    if (M4 || total <= UAM_MCTS_QCAP(K)) {
+#if (UAM_MCTS_ABL & 32)
+        {   /* development: the frame loop twice, the first time on a copy of the state */
+            MctsState<K> s2 = s;
+            int fe2;
+            uint32_t f2 = mcts_frames<K, MODEL, PN>(rng, lane, sp, s2, o, chg, qbuf, fe2);
+            asm volatile("" :: "v"(s2.x[0]), "v"(s2.y[0]), "s"(f2), "s"(fe2));
+        }
+#endif
+        flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbuf, fe);
+    }
     else flags = mcts_frames_slow<K, PN>(rng, lane, sp, s, o, chg, fe);
     s.ox = lane_bcast(o.ox, fe + 1); s.oy = lane_bcast(o.oy, fe + 1);
     s.ovx = lane_bcast(o.vx, fe + 1); s.ovy = lane_bcast(o.vy, fe + 1);
@@ -685,14 +700,18 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
                 break;
             }
             /* best_child(c_param), common.py:47-52: lanes 0..8 weigh one child each, first maximum wins */
-            const double logn = uam_log_k(t.n[v]);
+            int best = lane;
+            UAM_MCTS_REPEAT(128) {
+            double nv = t.n[v];
+            if (rep_) asm volatile("" : "+v"(nv));
+            const double logn = uam_log_k(nv);
             double w = -1.0e300;
             if (lane < 9) {
                 const int c = t.child[v][lane];
                 const double cn = t.n[c];
                 w = (t.q[c] / cn) + c_param * __builtin_sqrt((2 * logn / cn));
             }
-            int best = lane;
+            best = lane;
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) {
                 const double w2 = __shfl_xor(w, o);
@@ -700,6 +719,7 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
                 if (w2 > w || (w2 == w && b2 < best)) { w = w2; best = b2; }
             }
             best = lane_bcast(best, 0);
+            }
             v = t.child[v][best];
         }
         /* ---- rollout, nodes_single_randintru.py:212-218 */

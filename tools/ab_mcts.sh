@@ -7,7 +7,7 @@ for v in "$@"; do
   for shape in "8192 64" "2048 20"; do
     set -- $shape
     echo -n "$v $shape " >> $OUT
-    timeout -k 10 120 python tools/bench_mcts.py --batch $1 --intruders $2 --cpu-roots 0 2>&1 | grep gpu_ms | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('%.3f ms' % d['gpu_ms_per_batched_decision'])" >> $OUT
+    timeout -k 10 120 python tools/bench_mcts.py --batch $1 --intruders $2 --cpu-roots 0 --model ${MCTS_MODEL:-randintru} 2>&1 | grep gpu_ms | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('%.3f ms' % d['gpu_ms_per_batched_decision'])" >> $OUT
   done
 done
 cat $OUT
