@@ -127,3 +127,23 @@ def test_host_infos_sequences(capi):
     assert "episode" not in h[0] and h[2]["episode"] == {"r": 1.5, "l": 120, "t": 12.5}
     assert h.episodes() == [(2, 1.5, 120), (3, -1.0, 7), (4, -0.5, 33)]
     assert uamenv.HostInfos(codes, done, None, None, 0.0).episodes() == []
+
+
+def test_bad_planner_config_is_rejected_before_touching_a_device(capi):
+    """uam_mcts_best_action / uam_mcts_move validate the configuration first: a bad one is UAM_EINVAL (-22) with a
+    message on a box without a GPU too.  simulate_frame is bounded by the wave: one lane per frame of a move plus one
+    for the state before it."""
+    lib = capi.lib()
+    for field, value, word in (("simulate_frame", 64, "simulate_frame"), ("simulate_frame", 0, "simulate_frame"),
+                               ("simulations", 255, "simulations"), ("search_depth", 0, "search_depth"),
+                               ("num_intruders", 257, "num_intruders"), ("model", 7, "model")):
+        cfg = capi.UamMctsConfig()
+        assert lib.uam_mcts_config_default(C.byref(cfg), 8) == 0
+        setattr(cfg, field, value)
+        assert lib.uam_mcts_workspace_bytes(C.byref(cfg), 4) == -1
+        assert word in lib.uam_last_error().decode(), (field, lib.uam_last_error())
+        rc = lib.uam_mcts_best_action(C.byref(cfg), 0, None, 4, 0, None, None, None, None, None)
+        assert rc == -22 and word in lib.uam_last_error().decode()
+    cfg = capi.UamMctsConfig()
+    assert lib.uam_mcts_config_default(C.byref(cfg), 8) == 0 and cfg.simulate_frame == 10 and cfg.simulations == 100
+    assert lib.uam_mcts_workspace_bytes(C.byref(cfg), 4) == 4 * 101 * (5 * 64 + 8) * 8
