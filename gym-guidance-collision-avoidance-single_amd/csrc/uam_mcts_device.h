@@ -23,6 +23,13 @@
  * heading-change draws per FRAME QUAD: word frame&3 of the block is the Bernoulli uniform p and a change takes its
  * second uniform as p / hc_prob (uniform on [0,1) given p < hc_prob).  Zero sigmas (the shipped MCTS config has position_sigma =
  * speed_sigma = 0) draw nothing: adding N(0,0) is the identity.
+ *
+ * What bounds it: vector-instruction issue (the vector ALU is busy ~75 % of the time at four waves per SIMD), so the
+ * kernel is written for few vector instructions per move (round 3): the move in sections that each read
+ * their parameters afresh from the kernarg segment (scalar loads; the by-value block plus the search state overflowed
+ * the 102 SGPRs, and every spilled SGPR comes back through a v_readlane); the ownship noise of several simulations drawn
+ * in one lane-parallel pass into an LDS table; heading changes marked per frame with a compare and settled by a per-lane
+ * walk over the set bits plus a dense sincos of the queue; the ownship recurrences walked through the lanes by DPP.
  */
 #ifndef UAM_MCTS_DEVICE_H
 #define UAM_MCTS_DEVICE_H
