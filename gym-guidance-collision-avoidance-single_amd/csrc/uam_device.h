@@ -1387,24 +1387,27 @@ __device__ inline void reset_env(const UamParams& p, int env, int gl, bool quad_
  * reset() draws 8 N + 4 words of the env's stream (+ 4 per rejected position) IN INTRUDER ORDER.  Walking the
  * intruders one after the other (reset_env above) made the one wave of a launch that resets a 25-30 us straggler, and
  * the slowest wave is what a launch takes.  Here instead
- *   - the WHOLE WAVE twists the next <= 224 words of the resetting env's stream into a per-wave LDS buffer in one
- *     memory round trip (any <= 227 consecutive words are independent; a span runs over the end of a round into the
- *     next one when the reset is certain to consume past it), and
- *   - the env's lane group draws its quads IN PARALLEL from the buffer: intruder i's words start at
- *     8 i + 4 (rejections before i), so every lane guesses "no rejections before me", counts the words its four
- *     intruders take from there, the group takes the exclusive prefix sum and lanes whose start moved count again —
- *     lane 0 is right after one pass, every lane whose predecessors are right is right after the next: typically 1-2
- *     passes.  Guesses are never too high, so a lane that runs off the buffer at its guess runs off it at its true
- *     start too: the lanes before the first such lane are complete and draw once more for keeps, that lane itself
- *     (its start is exact) keeps what fitted — down to "inside the rejection loop of slot j" — the cursor advances
- *     by those words and the next segment resumes there.  The goal's four words belong to the last quad's lane.
+ *   - the WHOLE WAVE twists the next words of the resetting env's stream into a per-wave LDS buffer — up to two chunks
+ *     of 224 (any <= 227 consecutive words are independent; the second chunk's loads are issued behind the first one's
+ *     stores; a chunk runs over the end of a round into the next one when the reset is certain to consume past it), and
+ *   - the WHOLE WAVE draws the env's intruders IN PARALLEL from the buffer, worker lane v the intruders S v .. S v + S - 1
+ *     (S = ceil(N / 64): one per lane up to N = 64), whichever env's lane group the lane belongs to: intruder i's words
+ *     start at 8 i + 4 (rejections before i), so every worker guesses "no rejections before me", counts the words its
+ *     intruders take from there, the wave takes the exclusive prefix sum (six DPP additions) and workers whose start
+ *     moved count again — worker 0 is right after one pass, every worker whose predecessors are right is right after
+ *     the next: 4.1 passes on average at N = 32 (one more per rejected position, roughly).  A worker that runs off the
+ *     buffer at its settled start stops there: the workers before the first such one are complete and draw once more
+ *     for keeps (slot records in LDS), that worker itself keeps what fitted — down to "inside the rejection loop of
+ *     slot j" — the cursor advances by those words and the next segment resumes there.  The goal's four words belong
+ *     to the last worker; the env's own lanes pick their quads up from the slot records afterwards.
  * Every segment over a full buffer consumes at least four words, so this ends when the reference's own loop ends.
  * Bit-identical to reset_env (the same arithmetic on the same words).
+ * (Round 2 had the env's own L = N / 4 lanes draw four intruders each, one after the other, from one 224-word chunk per
+ * segment: a lone wave's chain of dependent fp64 operations over twice as many passes — the 25 us straggler that rounds
+ * 2 and 3 took for instruction-cache misses; profiles/r03_mt_mode.md.)
  * Written for few code bytes and few registers, INLINE: rolled slot loops with the per-slot results in LDS (a lane's
- * quad is in registers under compile-time indices only).  The first version of this, out of line over a scratch
- * record, was as slow as the serial walk: every call boundary drains the vector-memory counter — the step's
- * outstanding stores included — and unrolled fp64 slot code is 20 KB of instruction-cache misses for a path that one
- * wave in a few hundred runs. */
+ * quad is in registers under compile-time indices only); a call boundary would drain the vector-memory counter — the
+ * step's outstanding stores included. */
 #define UAM_MT_BIG 224            /* words twisted in parallel by one chunk (any <= 227 consecutive words are independent) */
 #define UAM_MT_BUF (2 * UAM_MT_BIG)   /* the reset's word buffer: two chunks, the second behind the first one's stores */
 #define UAM_MT_SLOT_BYTES 48      /* x, y, speed, heading (float64), vx, vy (float32), promoted (uint32) of one new intruder */
