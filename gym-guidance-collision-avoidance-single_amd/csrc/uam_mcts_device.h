@@ -78,9 +78,10 @@ struct UamMctsParams {
 
 typedef const __attribute__((address_space(4))) UamMctsParams MctsParamsK;   /* the block where it lives: the kernarg segment */
 
-/* tree bookkeeping of one root (one wave) in LDS: 38 B per node */
+/* tree bookkeeping of one root (one wave) in LDS: 32 B per node */
 template <int CAP> struct MctsTree {
-    double n[CAP], q[CAP], rew[CAP];
+    double q[CAP], rew[CAP];
+    uint16_t n[CAP];                      /* visit counts (<= simulations: exact as integers, converted where common.py divides by them) */
     uint8_t parent[CAP], nchild[CAP], depth[CAP], term[CAP], act[CAP];
     uint8_t child[CAP][9];
 };
@@ -640,9 +641,22 @@ __device__ __forceinline__ void mcts_load_node(const double* pint, const double*
     s.ox = o[0]; s.oy = o[1]; s.ovx = o[2]; s.ovy = o[3]; s.osp = o[4]; s.ohd = o[5];
 }
 
+/* best_child needs log(n) of a node's visit count at every level of every descent (common.py:50): n is an integer below
+ * the tree's capacity, so the block computes the table once (the same uam_log_k of the same values) and a descent reads
+ * it from LDS instead of running the ~45 vector instructions of a log. */
+#ifndef UAM_MCTS_LOGTAB
+#define UAM_MCTS_LOGTAB 1
+#endif
+__device__ __forceinline__ void mcts_fill_logtab(double* logtab, const int cap)
+{
+    if (UAM_MCTS_LOGTAB)
+        for (int i = threadIdx.x; i < cap; i += blockDim.x) logtab[i] = i > 0 ? uam_log_k((double)i) : 0.0;
+    __syncthreads();
+}
+
 /* MCTS(root).best_action(sims, depth), search_single.py:8-22 — one wave per root */
 template <int K, int MODEL, bool PN, int CAP>
-__device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf, double* const ntab)
+__device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf, double* const ntab, const double* const logtab)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int root = blockIdx.x * UAM_MCTS_WAVES_PER_BLOCK + wv;
@@ -657,7 +671,7 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
     mcts_load_root<K>(p, p.roots + (size_t)root * (p.width * p.N + 8), lane, rs, sp, gx, gy);
     mcts_store_node<K>(pint, pown, 0, lane, rs);
     for (int i = lane; i < p.cap; i += 64) {
-        t.n[i] = 0.0; t.q[i] = 0.0; t.rew[i] = 0.0;
+        t.n[i] = 0; t.q[i] = 0.0; t.rew[i] = 0.0;
         t.parent[i] = 255; t.nchild[i] = 0; t.depth[i] = 0; t.term[i] = 0; t.act[i] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -709,13 +723,13 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
             /* best_child(c_param), common.py:47-52: lanes 0..8 weigh one child each, first maximum wins */
             int best = lane;
             UAM_MCTS_REPEAT(128) {
-            double nv = t.n[v];
+            int nv = (int)t.n[v];
             if (rep_) asm volatile("" : "+v"(nv));
-            const double logn = uam_log_k(nv);
+            const double logn = UAM_MCTS_LOGTAB ? logtab[nv] : uam_log_k((double)nv);  /* log of a visit count: from the block's table */
             double w = -1.0e300;
             if (lane < 9) {
                 const int c = t.child[v][lane];
-                const double cn = t.n[c];
+                const double cn = (double)t.n[c];
                 w = (t.q[c] / cn) + c_param * __builtin_sqrt((2 * logn / cn));
             }
             best = lane;
@@ -746,16 +760,16 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
             r = mcts_reward<K>(mcts_params(), s, gx, gy, flags);
         }
         /* ---- backpropagate (every lane writes the same values: wave-uniform LDS update) */
-        for (int u = v; u != 255; u = t.parent[u]) { t.n[u] += 1.; t.q[u] += r; }
+        for (int u = v; u != 255; u = t.parent[u]) { t.n[u] = (uint16_t)(t.n[u] + 1); t.q[u] += r; }
     }
     /* best_child(c_param = 0.) of the root */
     {
         double w = -1.0e300;
         const int nc = t.nchild[0];
-        const double logn = uam_log_k(t.n[0]);
+        const double logn = UAM_MCTS_LOGTAB ? logtab[(int)t.n[0]] : uam_log_k((double)t.n[0]);
         if (lane < nc) {
             const int c = t.child[0][lane];
-            const double cn = t.n[c];
+            const double cn = (double)t.n[c];
             w = (t.q[c] / cn) + 0. * __builtin_sqrt((2 * logn / cn));
         }
         int best = lane;
@@ -776,7 +790,7 @@ __device__ __forceinline__ void mcts_search(MctsTree<CAP>& t, double* const qbuf
             const bool has = lane < nc;
             const int c = has ? t.child[0][lane] : 0;
             if (pe.child_q_out) pe.child_q_out[9 * (size_t)root + lane] = has ? t.q[c] : 0.0;
-            if (pe.child_n_out) pe.child_n_out[9 * (size_t)root + lane] = has ? t.n[c] : 0.0;
+            if (pe.child_n_out) pe.child_n_out[9 * (size_t)root + lane] = has ? (double)t.n[c] : 0.0;
         }
     }
 }
@@ -792,7 +806,9 @@ __global__ void UAM_MCTS_BOUNDS uam_mcts_search_kernel(const UamMctsParams p)
     __shared__ MctsTree<UAM_MCTS_MAX_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(K)];
     __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
-    mcts_search<K, MODEL, PN, UAM_MCTS_MAX_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
+    __shared__ double logtab[UAM_MCTS_MAX_NODES];
+    mcts_fill_logtab(logtab, UAM_MCTS_MAX_NODES);
+    mcts_search<K, MODEL, PN, UAM_MCTS_MAX_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6], logtab);
 }
 
 template <int MODEL, bool PN>
@@ -802,7 +818,9 @@ uam_mcts_search_small_kernel(const UamMctsParams p)
     __shared__ MctsTree<UAM_MCTS_SMALL_NODES> trees[UAM_MCTS_WAVES_PER_BLOCK];
     __shared__ double queues[UAM_MCTS_WAVES_PER_BLOCK][MODEL == UAM_MCTS_MODEL_STRAIGHT4 ? 1 : 3 * UAM_MCTS_QCAP(1)];
     __shared__ double noise[UAM_MCTS_WAVES_PER_BLOCK][UAM_MCTS_NZ_DOUBLES];
-    mcts_search<1, MODEL, PN, UAM_MCTS_SMALL_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6]);
+    __shared__ double logtab[UAM_MCTS_SMALL_NODES];
+    mcts_fill_logtab(logtab, UAM_MCTS_SMALL_NODES);
+    mcts_search<1, MODEL, PN, UAM_MCTS_SMALL_NODES>(trees[threadIdx.x >> 6], queues[threadIdx.x >> 6], noise[threadIdx.x >> 6], logtab);
 }
 
 /* one move() per state, no tree: parity / building block */
