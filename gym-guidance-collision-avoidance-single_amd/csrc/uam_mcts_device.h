@@ -39,7 +39,9 @@
 #define UAM_MCTS_MAX_NODES 256          /* simulations + 1 <= 256 (node ids are bytes) */
 #define UAM_MCTS_SMALL_NODES 128        /* tree capacity of the small instances (simulations <= 126) */
 #define UAM_MCTS_MAX_SLOTS 4            /* intruders per lane: N <= 256 */
+#ifndef UAM_MCTS_WAVES_PER_BLOCK
 #define UAM_MCTS_WAVES_PER_BLOCK 2
+#endif
 #ifndef UAM_MCTS_ABL
 #define UAM_MCTS_ABL 0                  /* development builds only: bit mask of sections executed TWICE (same results; the time added is the section's cost) */
 #endif
