@@ -546,8 +546,21 @@ def ensure_built():
         pass            # no make here: uamenv raises a clear ImportError if the library really is missing
 
 
+def under_profiler():
+    """True when a profiler's preloaded library shares this process (rocprofv3 exports ROCPROF* and preloads
+    librocprofiler-sdk-tool.so): with --pmc it initialises the GPU before Python starts, and a GPU-initialised process
+    must not spawn children here (ensure_built's `make`, the CPU baseline's worker threads are fine, a fork+exec is not)."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+
+
 def main():
     args = parse_args()
+    if under_profiler():
+        # a profiled run measures kernels, not the job: no child processes, no seconds-long closing pass
+        args.no_build = True
+        args.sustain_seconds = 0.0
     if "WORLD_SIZE" not in os.environ and not args.no_build:
         ensure_built()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -320,7 +320,7 @@ __device__ __forceinline__ void mt_store(const UamDev& s, int e, const MtCtx& m)
 typedef __attribute__((address_space(3))) uint32_t* UAM_LDS_U32W;
 template <int U = 4>
 __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, const int gen, const int len, const int gl,
-                                              const int L, UAM_LDS_U32W win, unsigned long long* dbg = nullptr, const bool dry = false)
+                                              const int L, UAM_LDS_U32W win, unsigned long long* dbg = nullptr)
 {
     /* BRANCH-FREE inside a chunk: with `if (k >= gen) { twist; store }` the value of word k reached the LDS write from
      * two paths (loaded / computed), and at that merge the compiler waits for vmcnt(0) — on the computed path that is
@@ -352,7 +352,7 @@ __device__ __forceinline__ void mt_twist_span(uint32_t* key, const int pos, cons
             const uint32_t vt = c[u] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
             const uint32_t v = k >= gen ? vt : a[u];
             if (i < len) {
-                if (!dry) key[k] = v;          /* (dry: the code-warming run of mt_epilogue_fn leaves the stream alone) */
+                key[k] = v;
                 win[i] = mt_temper(v);
             }
         }
@@ -788,12 +788,15 @@ __device__ __forceinline__ int wave_scan_add(int x)
 
 /* The 32-bit integer reductions of the sweep (first NMAC index, packed conflict counts): one DPP-modified VALU instruction
  * per butterfly level, v = op(perm(v), v), instead of the copy + hazard nop + v_mov_dpp + op the compiler emits for the
- * generic form (it does not fold the permutation into the consumer).  s_nop 1: a DPP operand written by the previous VALU
- * instruction needs two wait states.  A lane whose source lane is switched off keeps its own value, as in the generic form. */
+ * generic form (it does not fold the permutation into the consumer).  The compiler's hazard recognizer does not see into
+ * the asm, so the wait states are spelt out for the worst case: s_nop 4 in front of the FIRST level (a VALU write of EXEC —
+ * v_cmpx — needs five wait states before a DPP instruction, a VALU write of the operand two), s_nop 1 between levels (the
+ * operand was written by the previous level; nothing in between can touch EXEC).  A lane whose source lane is switched
+ * off keeps its own value, as in the generic form. */
 #define UAM_DPP_OP(NAME, OPC)                                                                                                    \
     __device__ __forceinline__ uint32_t NAME(uint32_t v, int L)                                                                  \
     {                                                                                                                            \
-        if (L >= 2) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));      \
+        if (L >= 2) asm volatile("s_nop 4\n\t" OPC " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));      \
         if (L >= 4) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));      \
         if (L >= 8) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));          \
         if (L >= 16) asm volatile("s_nop 1\n\t" OPC " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));              \
@@ -1281,11 +1284,11 @@ __device__ __forceinline__ void obs_emit(const UamParams& p, float* stage, int e
 /* the tail of reset(): the per-env fields (lane 0 of the group) and the obs tail of the new episode */
 __device__ __forceinline__ void reset_finish(const UamParams& p, int env, int gl, uint32_t rc, float oxf, float oyf, double ohd,
                                              double osp, double ovx, double ovy, double gx, double gy, float* tail,
-                                             float& rox, float& roy, const bool dry = false)
+                                             float& rox, float& roy)
 {
     /* every lane of the group has read reset_count; the group is one wave-resident unit */
     __builtin_amdgcn_wave_barrier();
-    if (gl == 0 && !dry) {
+    if (gl == 0) {
         p.s.own_x[env] = oxf; p.s.own_y[env] = oyf;
         p.s.own_h[env] = ohd; p.s.own_s[env] = osp;
         p.s.own_vx[env] = ovx; p.s.own_vy[env] = ovy;
@@ -1510,7 +1513,7 @@ __device__ __forceinline__ int mt_slots_from_buffer(const UamParams& p, const UA
 template <bool POS64, bool SH, bool ROS, bool KC>
 __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool need, const int env, const int gl, const int L,
                                               const bool quad_ok, MtWin& m, Quad<POS64, SH>& q, float* tail, float& rox,
-                                              float& roy, uint32_t* lds, unsigned long long* st = nullptr, const bool dry = false)
+                                              float& roy, uint32_t* lds, unsigned long long* st = nullptr)
 {
 #if UAM_STAMP
     unsigned long long rs_last = __builtin_amdgcn_s_memtime();
@@ -1569,9 +1572,9 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
                     const int plen = part ? len2 : len1;
                     const int pgen = (part || nextr) ? gen_next : gen;
 #if UAM_STAMP
-                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), st + 4, dry);
+                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), st + 4);
 #else
-                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), nullptr, dry);
+                    if (plen > 0) mt_twist_span<4>(key, part ? 0 : cpos, pgen, plen, lane, 64, (UAM_LDS_U32W)lds + blen + (part ? len1 : 0), nullptr);
 #endif
                 }
                 if (nextr) gen_next = max(gen_next, cpos + len1);
@@ -1655,7 +1658,7 @@ __device__ __forceinline__ void reset_wave_mt(const UamParams& p, const bool nee
                 }
             }
             q.flags = promm;                   /* new objects: conflict flags cleared */
-            reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy, dry);
+            reset_finish(p, env, gl, rc, oxf, oyf, ohd, osp, ovx, ovy, gx, gy, tail, rox, roy);
         }
         UAM_WAVE_LDS_RELEASE();                     /* (the next resetting env of this wave reuses the records) */
     }

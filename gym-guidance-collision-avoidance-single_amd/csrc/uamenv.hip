@@ -42,7 +42,6 @@ struct uam_env {
     int many_resident_blocks;   /* blocks of the looped kernel (ownship-wave flavour) the device holds at once (0: no such instance) */
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
     int many3_resident_blocks;  /* the same for the three-wave form (0: the handle's geometry has no such instance) */
-    int many3_kco;              /* (kept for the development override; only flavour 1 is instantiated) */
     int Tm3, Em3;               /* three-wave form: sweeping threads and envs per block (Em3 <= Tm3 / L) */
     bool shared_stream;         /* UAM_RNG_MT19937_SHARED: cfg.rng_mode is normalised to UAM_RNG_MT19937, every env uses stream 0 */
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
@@ -75,6 +74,12 @@ struct uam_env {
     int64_t timed_launches;
     uint32_t policy_calls;
     uint32_t* policy_row;       /* [2B] scratch action row of uam_rollout_policy's queued-launch form */
+    /* development overrides, read from the environment ONCE in uam_create (never on the launch path: getenv scans
+     * environ and races with a host application's setenv) */
+    int ovr_many;               /* UAMENV_MANY: 0 unset, 1 off, 2 force, 3 force4 */
+    bool ovr_many3_off;         /* UAMENV_MANY3=off */
+    bool ovr_many4_generic;     /* UAMENV_MANY4_GENERIC */
+    int ovr_inline_noise;       /* UAMENV_INLINE_NOISE: -1 unset, else 0 / 1 */
 };
 
 static UamSweepFn many_fn(const uam_env* e);
@@ -83,7 +88,7 @@ static inline size_t lds_step(const uam_env* e, bool staged);
 static bool many_instance_exists(const uam_env* e);
 static UamSweepFn many4_fn(const uam_env* e);
 static inline size_t lds_many(const uam_env* e, int fl, bool staged);
-static UamSweepFn many3_fn(const uam_env* e, int kco = -1);
+static UamSweepFn many3_fn(const uam_env* e);
 static inline size_t lds_many3(const uam_env* e);
 static inline int grid_many(const uam_env* e, int fl);
 static inline int grid_many3(const uam_env* e);
@@ -338,6 +343,11 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->policy_calls = 0;
     e->policy_row = nullptr;
     e->step_index = 0;
+    e->ovr_many = 0; e->ovr_many3_off = false; e->ovr_many4_generic = false; e->ovr_inline_noise = -1;
+    if (const char* f = getenv("UAMENV_MANY")) e->ovr_many = !strcmp(f, "off") ? 1 : !strcmp(f, "force") ? 2 : !strcmp(f, "force4") ? 3 : 0;
+    if (const char* f = getenv("UAMENV_MANY3")) e->ovr_many3_off = !strcmp(f, "off");
+    e->ovr_many4_generic = getenv("UAMENV_MANY4_GENERIC") != nullptr;
+    if (const char* v = getenv("UAMENV_INLINE_NOISE")) e->ovr_inline_noise = atoi(v) != 0 ? 1 : 0;
     e->ktiming = false;
     e->ksamples = 0;
     e->noise = nullptr;
@@ -381,10 +391,23 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
         }
         e->mt_win = (e->mt_win + 1) & ~1;
     }
-    e->Tm = T < 64 * L ? T : 64 * L;      /* the ownship wave has one lane per env of the block */
-    e->Em = e->Tm / L;
     e->D = uam_obs_dim(cfg);
     e->hold_sh = (cfg->dynamics == UAM_DYN_RANDINTRUDER || cfg->obs_mode == UAM_OBS_RAW6) ? 1 : 0;
+    {
+        /* the step block's dynamic LDS (observation staging + ownship records + MT19937: stream windows and one reset
+         * area per wave) must fit a workgroup's share: MT19937 with N = 256 and T = 256 is 76.7 KB.  Smaller blocks
+         * while it does not, a clear error if even one wave per block is too much */
+        const size_t lds_cap = prop.sharedMemPerBlock > 0 ? (size_t)prop.sharedMemPerBlock : (size_t)65536;
+        while (lds_step(e, true) > lds_cap && e->T > 64 && e->T > L) { e->T >>= 1; e->E = e->T / L; }
+        if (lds_step(e, true) > lds_cap) {
+            const size_t need = lds_step(e, true);
+            delete e;
+            return fail(UAM_EINVAL, "step kernel needs %zu B of LDS per block of %d threads, the device allows %zu", need, T, lds_cap);
+        }
+        T = e->T;
+    }
+    e->Tm = T < 64 * L ? T : 64 * L;      /* the ownship wave has one lane per env of the block */
+    e->Em = e->Tm / L;
     /* Philox configurations run the ownship phase inside the sweep launch (one launch per step); the
      * MT19937 stream and the random-ownship-start variant keep the separate ownship kernel */
 
@@ -450,6 +473,9 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     }
     e->step_kernel = step_fn(e);
     if (getenv("UAMENV_DEBUG")) {
+        fprintf(stderr, "[uamenv] arrays: px %p py %p vx %p vy %p qf %p own_x %p own_h %p goal_x %p noise %p (%zu B per intruder array)\n",
+                e->s.px, e->s.py, (void*)e->s.vx, (void*)e->s.vy, (void*)e->s.qf, (void*)e->s.own_x, (void*)e->s.own_h,
+                (void*)e->s.goal_x, (void*)e->noise, BI * 4);
         int per_cu = -1;
         hipFuncAttributes fa;
         memset(&fa, 0, sizeof(fa));
@@ -462,7 +488,6 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->many_resident_blocks = 0;
     e->many4_resident_blocks = 0;
     e->many3_resident_blocks = 0;
-    e->many3_kco = 1;
     e->Tm3 = 64; e->Em3 = 0;
     e->many_obs_direct = 0;
     if (!rc && many_instance_exists(e)) {
@@ -486,19 +511,18 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
             for (int E3 = want; E3 <= emax && E3 <= 64; E3 <<= 1) {
                 e->Em3 = E3;
                 e->Tm3 = E3 * e->L > 64 ? E3 * e->L : 64;
-                if (!many3_fn(e, 1)) { e->Em3 = 0; break; }
+                if (!many3_fn(e)) { e->Em3 = 0; break; }
                 per_cu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e, 1), e->Tm3 + 128, lds_many3(e)) != hipSuccess) per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e), e->Tm3 + 128, lds_many3(e)) != hipSuccess) per_cu = 0;
                 e->many3_resident_blocks = per_cu * e->num_cus;
                 if (grid_many3(e) <= e->many3_resident_blocks) break;
                 e->Em3 = 0;
             }
-            e->many3_kco = 1;
         }
         if (getenv("UAMENV_DEBUG"))
-            fprintf(stderr, "[uamenv] looped kernel: grid %d, resident blocks: ownship-wave flavour %d, three-wave form %d (flavour %d), "
+            fprintf(stderr, "[uamenv] looped kernel: grid %d, resident blocks: ownship-wave flavour %d, three-wave form %d, "
                     "no-ownship-wave flavour %d; three-wave geometry: %d envs, %d sweeping threads per block, grid %d\n", grid_many(e, 1),
-                    e->many_resident_blocks, e->many3_resident_blocks, e->many3_kco, e->many4_resident_blocks, e->Em3, e->Tm3,
+                    e->many_resident_blocks, e->many3_resident_blocks, e->many4_resident_blocks, e->Em3, e->Tm3,
                     e->Em3 ? grid_many3(e) : 0);
         if (const char* od = getenv("UAMENV_OBS_DIRECT")) e->many_obs_direct = atoi(od);   /* development override */
     }
@@ -624,7 +648,7 @@ static UamSweepFn heavy_many_fn(const uam_env* e)
 {
     if (e->cfg.rng_mode != UAM_RNG_PHILOX || e->cfg.precision != UAM_POS_EXACT || e->ktiming || e->env_step) return nullptr;
     if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return nullptr;
-    if (const char* f = getenv("UAMENV_MANY")) { if (!strcmp(f, "off")) return nullptr; }
+    if (e->ovr_many == 1) return nullptr;
     if (e->cfg.obs_mode == UAM_OBS_KNN5 || e->cfg.shaped_reward) return nullptr;     /* (the HER variants loop over single steps) */
     if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) return heavy_many_ros<UAM_MODE_RI, true>(e);
     if (e->hold_sh) return heavy_many_ros<0, true>(e);
@@ -636,7 +660,7 @@ static UamSweepFn mt_many_fn(const uam_env* e)
 {
     if (e->cfg.rng_mode != UAM_RNG_MT19937 || e->shared_stream || e->ktiming) return nullptr;
     if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return nullptr;
-    if (const char* f = getenv("UAMENV_MANY")) { if (!strcmp(f, "off")) return nullptr; }
+    if (e->ovr_many == 1) return nullptr;
     return mt_kernel(e, true);
 }
 
@@ -685,18 +709,16 @@ static UamSweepFn many4_fn(const uam_env* e)
 /* the three-wave form (uam_sweep_many3_kernel: sweeping waves + ownship wave + copy wave, compile-time lane-group width):
  * plain step, full quads (N = 4 L, L a power of two), four floats per intruder in the observation */
 template <int LC>
-static UamSweepFn many3_fn_l(const uam_env* e, int kco)
+static UamSweepFn many3_fn_l(const uam_env* e)
 {
-    (void)kco;        /* (only the flavour with the ownship literals pinned to SGPRs is instantiated: uam_device.h, KCO) */
     if (e->cfg.obs_mode == UAM_OBS_RAW4) return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_RAW4, true>;
     return uam_sweep_many3_kernel<0, false, LC, UAM_OBS_NORM4, true>;
 }
-static UamSweepFn many3_fn(const uam_env* e, int kco)
+static UamSweepFn many3_fn(const uam_env* e)
 {
     if (!many_instance_exists(e) || e->cfg.shaped_reward || e->cfg.random_own_start || e->cfg.track_episodes) return nullptr;
     if (e->cfg.num_intruders != 4 * e->L) return nullptr;          /* full quads, and Q = L */
     if (e->Tm3 > 128 || e->Em3 < 1) return nullptr;                /* the copy wave holds T / 16 <= 8 slots per lane */
-    if (kco < 0) kco = e->many3_kco;
     if (e->cfg.dynamics == UAM_DYN_RANDINTRUDER) {
         /* RandIntruder: held speed / heading, six-wide raw rows (the variant's only observation) */
         if (e->cfg.obs_mode != UAM_OBS_RAW6) return nullptr;
@@ -709,10 +731,10 @@ static UamSweepFn many3_fn(const uam_env* e, int kco)
     if (e->hold_sh) return nullptr;
     if (e->cfg.obs_mode != UAM_OBS_NORM4 && e->cfg.obs_mode != UAM_OBS_RAW4) return nullptr;
     switch (e->L) {
-    case 2: return many3_fn_l<2>(e, kco);
-    case 4: return many3_fn_l<4>(e, kco);
-    case 8: return many3_fn_l<8>(e, kco);
-    case 16: return many3_fn_l<16>(e, kco);
+    case 2: return many3_fn_l<2>(e);
+    case 4: return many3_fn_l<4>(e);
+    case 8: return many3_fn_l<8>(e);
+    case 16: return many3_fn_l<16>(e);
     default: return nullptr;
     }
 }
@@ -756,11 +778,9 @@ static inline size_t lds_many(const uam_env* e, int fl, bool staged)
 static int many_flavour(const uam_env* e)
 {
     if (!many_instance_exists(e) || e->ktiming || e->env_step) return 0;
-    if (const char* f = getenv("UAMENV_MANY")) {       /* development override: off / force / force4 */
-        if (!strcmp(f, "off")) return 0;
-        if (!strcmp(f, "force")) return 1;
-        if (!strcmp(f, "force4")) return many4_fn(e) ? 2 : 0;
-    }
+    if (e->ovr_many == 1) return 0;                     /* development override: off / force / force4 */
+    if (e->ovr_many == 2) return 1;
+    if (e->ovr_many == 3) return many4_fn(e) ? 2 : 0;
     if (e->cfg.fuse_rollout == UAM_FUSE_NEVER) return 0;
     if (grid_many(e, 1) <= e->many_resident_blocks) return 1;
     if (e->many4_resident_blocks > 0 && grid_many(e, 2) <= e->many4_resident_blocks) return 2;
@@ -778,7 +798,7 @@ static bool use_many3(const uam_env* e, const UamParams& p, int fl)
 {
     if (fl != 1 || e->Em3 < 1 || !many3_fn(e) || grid_many3(e) > e->many3_resident_blocks) return false;
     if (p.obs && !p.obs_vec) return false;
-    if (const char* f = getenv("UAMENV_MANY3")) { if (!strcmp(f, "off")) return false; }   /* development override */
+    if (e->ovr_many3_off) return false;                 /* development override */
     return true;
 }
 
@@ -812,7 +832,7 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
     }
 #endif
     UamSweepFn fn4 = many4_fn(e);
-    if (fl == 2 && many4_spec_fn(e) && (!p.obs || p.obs_vec) && !getenv("UAMENV_MANY4_GENERIC")) fn4 = many4_spec_fn(e);
+    if (fl == 2 && many4_spec_fn(e) && (!p.obs || p.obs_vec) && !e->ovr_many4_generic) fn4 = many4_spec_fn(e);
     hipLaunchKernelGGL(fl == 2 ? fn4 : (m3 ? many3_fn(e) : many_fn(e)), grid, block, lds, st, p);
 }
 
@@ -938,7 +958,7 @@ static int step_once(uam_env* e, const void* actions, float* obs_out, float* rew
          * inside the step kernel's ownship phase — one launch per step; a large one keeps the separate launch, which
          * takes the draw off the step's critical path */
         bool inline_noise = grid_of(e) <= 2 * e->num_cus && !e->shared_stream;
-        if (const char* v = getenv("UAMENV_INLINE_NOISE")) inline_noise = atoi(v) != 0;      /* development override */
+        if (e->ovr_inline_noise >= 0) inline_noise = e->ovr_inline_noise != 0;      /* development override */
         if (inline_noise) {
             p.noise = nullptr;
         } else {
@@ -1340,8 +1360,8 @@ extern "C" int uam_bench_copy(int device, const void* src_dev, void* dst_dev, in
     const size_t n16 = (size_t)nbytes / 16;
     /* one 16-byte element per thread, a grid as large as the buffer: 6.26 TB/s at 1.5 GB on MI355X (the guide's float4-copy
      * figure); grid-stride forms, whose threads touch addresses megabytes apart, measure 4.3-5.1 TB/s (tools/bench_copy.py) */
-    int shape = 1;
-    if (const char* sh = getenv("UAMENV_COPY_SHAPE")) shape = atoi(sh);      /* development: 0 grid-stride x4 over 2048 blocks, 1 flat, N > 1 grid-stride over N blocks */
+    static const int shape_env = getenv("UAMENV_COPY_SHAPE") ? atoi(getenv("UAMENV_COPY_SHAPE")) : 1;
+    const int shape = shape_env;      /* development: 0 grid-stride x4 over 2048 blocks, 1 flat, N > 1 grid-stride over N blocks */
     if (shape == 1) {
         hipLaunchKernelGGL(uam_copy_flat_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src_dev, (uint4*)dst_dev, n16);
     } else {

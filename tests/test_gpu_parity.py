@@ -77,6 +77,17 @@ def test_mt19937_matches_oracle(uamenv, oracle, variant, N, T):
                     check_state_every=10)
 
 
+def test_mt19937_full_wave_envs_at_full_block_size(uamenv, oracle):
+    """N = 256 (one wave per env, four intruders per reset worker) with a batch large enough that the block keeps its
+    256 threads: the per-wave MT19937 reset areas then put the block's dynamic LDS above 64 KB (76.7 KB), the largest
+    any configuration asks for; uam_create checks it against the device's limit.  Random actions fly the ownship out of
+    the goal corridor slowly, so resets come from NMACs in the dense field."""
+    out = pu.run_lockstep(uamenv, oracle, 4096, 256, 12, policy="random", rng="mt19937", precision="exact",
+                          check_state_every=4)
+    assert out["spawns"] > 4096 * 256, "no respawn exercised"
+    assert out["counts"][2:].sum() > 0, "no episode end exercised: %s" % out["counts"]
+
+
 # ---------------------------------------------------------------- against the reference's own trajectories
 VARIANT_OF = {(0, 0, 0): "discrete9", (0, 2, 0): "continuous", (1, 1, 0): "mcts", (2, 1, 1): "randintruder",
               (0, 4, 0): "continuous2"}

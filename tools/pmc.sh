@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python $R/bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/$tag.log 2>&1 || echo "pass $tag failed"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python3 $R/bench.py --no-build --sustain-seconds 0 --no-secondary --steps 40 --warmup 20 --no-cpu-baseline > $OUT/$tag.log 2>&1 || echo "pass $tag failed"
 done
 cd $R
 python - <<PY

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp
 for v in her9 randintruder random_start; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${v}_$c -- python $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline --variant $v > $OUT/${v}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${v}_$c -- python3 $R/bench.py --no-build --sustain-seconds 0 --no-secondary --steps 60 --warmup 20 --no-cpu-baseline --variant $v > $OUT/${v}_$c.log 2>&1
   done
 done
 cd $R
