@@ -18,6 +18,7 @@ splits = [int(s) for s in sys.argv[4:]] or [1, 2, 4]
 variant = os.environ.get("PROBE_VARIANT", "discrete9")
 dev = torch.device("cuda", 0)
 reps = int(os.environ.get("PROBE_REPS", "12"))
+same_stream = os.environ.get("PROBE_SAME_STREAM", "0") == "1"     # the sub-batches take turns on ONE stream
 
 
 def run(S):
@@ -27,7 +28,7 @@ def run(S):
         e = uamenv.BatchedSingleAircraftEnv(Bs, N, variant=variant, seed=0, env_id_offset=s * Bs, fuse_rollout=2)
         e.reset()
         envs.append(e)
-        streams.append(torch.cuda.Stream(device=dev))
+        streams.append(torch.cuda.Stream(device=dev) if not (same_stream and s) else streams[0])
         tape = torch.randint(0, 9, (K, Bs), dtype=torch.int32, device=dev) if e.cfg.action_mode == 0 else \
             torch.rand((K, Bs), device=dev) * 2 - 1
         bufs.append((tape, torch.empty((K, Bs), dtype=torch.float32, device=dev),
@@ -55,7 +56,7 @@ def run(S):
     for e in envs:
         e.close()
     return {"streams": S, "envs_per_stream": Bs, "us_per_step_median": times[len(times) // 2], "us_per_step_min": times[0],
-            "G_env_steps_per_s": B / times[len(times) // 2] / 1e3}
+            "G_env_steps_per_s": B / times[len(times) // 2] / 1e3, "same_stream": same_stream}
 
 
 for S in splits:
