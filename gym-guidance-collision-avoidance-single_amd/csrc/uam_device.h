@@ -56,6 +56,9 @@
 #ifndef UAM_SWEEP_PRIO
 #define UAM_SWEEP_PRIO 3      /* s_setprio of the sweeping waves of the three-wave looped kernel */
 #endif
+#ifndef UAM_SPAWN_PRIO
+#define UAM_SPAWN_PRIO 2      /* ... and of its spawn wave */
+#endif
 #if UAM_STAMP
 #define UAM_NSTAMP 16
 #define UAM_STAMP_AT(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
@@ -195,6 +198,7 @@ struct UamParams {
     int32_t policy_kind;
     uint32_t policy_lo, policy_hi, policy_call;
     void* actions_out;
+    int32_t spawn_wave;           /* uam_sweep_many3_kernel: 1 = the block has a fourth wave that draws respawns ahead */
 };
 
 /* what the ownship phase hands to the env's lane group through LDS (48 B per env, three float4) */
@@ -2122,6 +2126,9 @@ struct OffBuf {
     bool had_reset;                                /* out: my env was reset in this step (its later ownship records are being redone) */
     float4 s0;                                     /* in: the first float4 of my env's record of THIS step, read ahead of the */
     bool have_s0;                                  /*     previous step's barrier (false: read it now) */
+    const float4* mb;                              /* in: this step's half of the spawn wave's mailbox, [thread][slot] = (x, y, vx, vy) */
+    const uint32_t* mtag;                          /*     and of its tags, [thread] = step << 4 | slots drawn (NULL: no spawn wave) */
+    bool distrust;                                 /* in: my env was reset one or two steps ago (the mailbox was drawn around stale records) */
 };
 template <bool POS64, int RNG, int MODE, bool SH, bool ROS, bool KC = false, bool PERSIST = false, bool OFFL = false>
 __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* lds_raw, const int k, float* const obs_k,
@@ -2327,11 +2334,32 @@ __device__ __forceinline__ void sweep_step(const UamParams& p, unsigned char* ld
     /* ---- respawn */
     if constexpr (RNG == UAM_RNG_PHILOX) {
         if (resp) { rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = PERSIST ? pk.step_index + (uint32_t)k : uam_step_of(pk, env, k);   /* (no graph-safe counter load in the looped kernel) */ rng.c_reset = 0; rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi; }
+        /* three-wave looped kernel with a spawn wave: the draw of a slot that was seen leaving the map two steps ahead
+         * is waiting in the mailbox (same counters, same ownship position: the same values); anything the spawn wave did
+         * not foresee, or drew around records that a reset has replaced since, is drawn here as before */
+        uint32_t drawn = 0;
+        if constexpr (OFFL && LEAN) {
+            if (resp && ob->mtag) {
+                const uint32_t tag = ob->mtag[tid];
+                drawn = ((tag >> 4) == (uint32_t)k && !ob->distrust) ? (tag & 0xFu) : 0u;
+            }
+        }
         while (resp) {                     /* lane-parallel: each lane serves its own pending slots */
             const int j = __ffs((int)resp) - 1;
             resp &= resp - 1;
-            P X, Y; bool prom; float vx, vy; double sp, hd;
-            spawn_intruder<POS64, RNG, LEAN, KC, (LEAN && OFFL)>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
+            P X = (P)0, Y = (P)0; bool prom = false; float vx = 0.f, vy = 0.f; double sp = 0.0, hd = 0.0;
+            bool have = false;
+            if constexpr (OFFL && LEAN) {
+                if ((drawn >> j) & 1u) {
+                    const float4 m = ob->mb[4 * tid + j];
+                    X = (P)m.x; Y = (P)m.y; vx = m.z; vy = m.w; prom = false; sp = 0.0; hd = 0.0;
+                    have = true;
+                }
+            }
+#if UAM_STAMP
+            if constexpr (PERSIST) { stamp_acc[4] += 1000ull * __popcll(__ballot(have)); stamp_acc[5] += 1000ull * __popcll(__ballot(!have)); }
+#endif
+            if (!have) spawn_intruder<POS64, RNG, LEAN, KC, (LEAN && OFFL)>(pk, rng, 4u * gl + j, false, ox, oy, X, Y, prom, vx, vy, sp, hd);
             q.set(j, X, Y, prom, vx, vy, sp, hd);
             vel_dirty = true; sp_dirty = true;
         }
@@ -2936,7 +2964,10 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     p.L = LC; p.lshift = LS; p.Q = LC; p.N = NC; p.Np = NC; p.D = DC; p.obs_w = OW; p.obs_vec = 1; p.obs_mode = OBSC;
     p.knn = 0; p.track_ep = 0; p.shaped = 0; p.obs_direct = 0;
     const int K = p.many_K;
-    const int T = (int)blockDim.x - 128;              /* sweeping threads; then the ownship wave, then the copy wave */
+    /* SPW: a fourth wave, the SPAWN WAVE, draws respawns ahead (plain step with an action tape, ownship batches of at
+     * least four steps: the record of step k + 1 is then final during the whole of step k) */
+    const bool spw = p.spawn_wave != 0;
+    const int T = (int)blockDim.x - (spw ? 192 : 128);  /* sweeping threads; then the ownship wave, the copy wave (, the spawn wave) */
     /* envs per block: at most T / L, and fewer where the host trades idle sweeping lanes for more blocks (small batches:
      * more of the chip busy) and for more lanes per env in the ownship wave (a longer batch of steps per pass) */
     const int E = p.E;
@@ -2954,9 +2985,80 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     uint32_t* const ack = (uint32_t*)(lds_raw + (size_t)ring * E * 48 + (size_t)E * 16 + (size_t)T * 32 * NARR);
     const bool two_bar = p.many_policy >= 0;
     const int SH4 = T * 4;
+    /* spawn wave's mailbox behind the handshake word: two halves of [T][4] float4 (x, y, vx, vy of a drawn slot), then two
+     * halves of [T] tags (step << 4 | slots drawn) */
+    float4* const mbx = (float4*)((unsigned char*)ack + 16);
+    uint32_t* const mtag = (uint32_t*)(mbx + 2 * SH4);
     float* const spx = slots; float* const spy = slots + 2 * SH4; float* const svx = slots + 4 * SH4; float* const svy = slots + 6 * SH4;
     float* const ssp = slots + 8 * SH4; float* const shd = slots + 10 * SH4;      /* (SH only; the row's field order) */
     const size_t slot_elems = (size_t)p.B * (size_t)DC;
+
+    if (spw && tid >= T + 128) {
+        /* ---------------- spawn wave.  A third of the sweeping wave's step is the respawn pass (one Philox block, a float32
+         * spawn and its rejection test for whichever lane has a slot that left the map: two wave-steps in three have one),
+         * and its draw depends on nothing the step computes: counters (env, step, slot, attempt) and the ownship's position
+         * in that step, which the ownship wave has recorded a batch ahead.  While the sweepers work on step k, this wave
+         * takes the state they parked after step k - 1, integrates it twice exactly as they will (no respawn, reset or
+         * NMAC cut foreseen: a prediction, never relied upon), and draws, for step k + 1, the slots it sees leaving the
+         * map then — into the mailbox half of step k + 1, tagged with the step.  The sweeping wave takes a drawn slot
+         * from the mailbox and draws anything else itself, so a wrong or missing prediction costs time, never values. */
+        if constexpr ((MODE & UAM_MODE_RI) == 0 && !SH) {
+            const int lane = tid - T - 128;
+            const UamParams& pk = p;
+            /* no tag of either half names a step of this launch until one is written (LDS holds whatever ran before) */
+            for (int t = lane; t < 2 * T; t += 64) mtag[t] = 0xFFFFFFFFu;
+            UAM_LDS_BARRIER();
+            /* what it draws is waited for at the end of the step: ahead of the ownship and copy waves it shares a SIMD with */
+            __builtin_amdgcn_s_setprio(UAM_SPAWN_PRIO);
+            int r3 = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int r3n = r3 + 1 == ring ? 0 : r3 + 1;
+                if (k >= 1 && k + 1 < K) {
+                    const int hp = (k - 1) & 1;               /* parked after step k - 1; the mailbox half of step k + 1 has the same parity */
+                    const float4* const rec_n = rec + 3 * E * r3n;
+#pragma unroll 1
+                    for (int t = lane; t < T; t += 64) {
+                        const int g = t >> LS, gl = t & (LC - 1);
+                        const int env = blockIdx.x * E + g;
+                        const bool ok = env < p.B && g < E;
+                        const float4 x4 = *(const float4*)(spx + hp * SH4 + 4 * t), y4 = *(const float4*)(spy + hp * SH4 + 4 * t);
+                        const float4 vx4 = *(const float4*)(svx + hp * SH4 + 4 * t), vy4 = *(const float4*)(svy + hp * SH4 + 4 * t);
+                        const float xs[4] = {x4.x, x4.y, x4.z, x4.w}, ys[4] = {y4.x, y4.y, y4.z, y4.w};
+                        const float vxs[4] = {vx4.x, vx4.y, vx4.z, vx4.w}, vys[4] = {vy4.x, vy4.y, vy4.z, vy4.w};
+                        uint32_t cand = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float x1 = xs[j] + vxs[j], y1 = ys[j] + vys[j];
+                            const float x2 = x1 + vxs[j], y2 = y1 + vys[j];
+                            const bool in1 = x1 >= 0.f && y1 >= 0.f && x1 <= p.W32 && y1 <= p.H32;
+                            const bool in2 = x2 >= 0.f && y2 >= 0.f && x2 <= p.W32 && y2 <= p.H32;
+                            cand |= ((ok && in1 && !in2) ? 1u : 0u) << j;
+                        }
+                        uint32_t drawn = 0;
+                        if (cand) {
+                            Rng<UAM_RNG_PHILOX> rng;
+                            rng.gid = pk.gid0 + (uint32_t)env; rng.c_step = pk.step_index + (uint32_t)(k + 1); rng.c_reset = 0;
+                            rng.k0 = pk.seed_lo; rng.k1 = pk.seed_hi;
+                            const float4 s0 = rec_n[3 * g];          /* the ownship in step k + 1 */
+                            while (cand) {
+                                const int j = __ffs((int)cand) - 1;
+                                cand &= cand - 1;
+                                float X, Y, vx, vy; bool prom; double sp, hd;
+                                spawn_intruder<false, UAM_RNG_PHILOX, true, false, true>(pk, rng, 4u * gl + j, false, s0.x, s0.y, X, Y, prom, vx, vy, sp, hd);
+                                mbx[(hp * T + t) * 4 + j] = make_float4(X, Y, vx, vy);
+                                drawn |= 1u << j;
+                            }
+                        }
+                        mtag[hp * T + t] = ((uint32_t)(k + 1) << 4) | drawn;
+                    }
+                }
+                UAM_LDS_BARRIER();                                               /* A: sweep k done */
+                r3 = r3n;
+            }
+        }
+        return;
+    }
 
     if (tid >= T + 64) {
         /* ---------------- copy wave */
@@ -3272,6 +3374,8 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
     ob.sp_prev = false;
     ob.have_s0 = false;
     ob.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    ob.mb = nullptr; ob.mtag = nullptr; ob.distrust = false;
+    bool rs1 = false, rs2 = false;        /* my env was reset in the previous step / the one before */
     UAM_LDS_BARRIER();
     /* the sweeping wave is the step's critical path; the ownship and copy waves that share its SIMD fill the issue
      * slots it leaves (VALU issue is arbitrated by priority, then age) */
@@ -3286,6 +3390,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         ob.out = outb + half * E;
         ob.sp = ssp + half * SH4; ob.hd = shd + half * SH4;
         ob.had_reset = false;
+        if (spw) { ob.mb = mbx + half * SH4; ob.mtag = mtag + half * T; ob.distrust = rs1 || rs2; }
 #if UAM_STAMP
         sweep_step<false, UAM_RNG_PHILOX, MODE, SH, ROS, true, true, true>(p, lds_raw, k, nullptr, q, vel_dirty, ncf, rec_k, nullptr, &ob, stamp_acc);
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
@@ -3295,6 +3400,7 @@ __device__ __forceinline__ void sweep_many3_body(const UamParams& p_in, unsigned
         /* the next step's record, ahead of the barrier: tape mode with batches of at least four steps only (the
          * ownship wave then finishes a batch's records at least one step before its first step; with a policy in the
          * launch it finishes the next record between the two barriers), and not for a wave that reset an env in this step */
+        rs2 = rs1; rs1 = ob.had_reset;
         ob.have_s0 = !two_bar && J >= 4 && !__ballot(ob.had_reset);
         if (ob.have_s0) ob.s0 = (rec + 3 * E * r3)[3 * (quad_ok ? g : 0)];
         UAM_LDS_BARRIER();                                                       /* A */

@@ -43,6 +43,7 @@ struct uam_env {
     int many4_resident_blocks;  /* the same for the flavour without ownship wave */
     int many3_resident_blocks;  /* the same for the three-wave form (0: the handle's geometry has no such instance) */
     int Tm3, Em3;               /* three-wave form: sweeping threads and envs per block (Em3 <= Tm3 / L) */
+    bool many3_spawn;           /* ... with a fourth wave that draws respawns ahead (tape-driven launches of the plain step) */
     bool shared_stream;         /* UAM_RNG_MT19937_SHARED: cfg.rng_mode is normalised to UAM_RNG_MT19937, every env uses stream 0 */
     int mt_win, mt_first;       /* MT19937: capacity of the per-env stream window in LDS / words twisted ahead at the head of a step */
     int many_obs_direct;        /* looped kernel: observation rows leave straight from registers (latency regime) */
@@ -92,6 +93,7 @@ static UamSweepFn many3_fn(const uam_env* e);
 static inline size_t lds_many3(const uam_env* e);
 static inline int grid_many(const uam_env* e, int fl);
 static inline int grid_many3(const uam_env* e);
+static inline size_t lds_many3_spawn(const uam_env* e);
 
 extern "C" const char* uam_last_error(void) { return g_err; }
 extern "C" const char* uam_version(void) { return "uamenv-hip 0.2 (gfx950, abi 2)"; }
@@ -489,6 +491,7 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
     e->many4_resident_blocks = 0;
     e->many3_resident_blocks = 0;
     e->Tm3 = 64; e->Em3 = 0;
+    e->many3_spawn = false;
     e->many_obs_direct = 0;
     if (!rc && many_instance_exists(e)) {
         int per_cu = 0;
@@ -518,12 +521,21 @@ extern "C" int uam_create(const uam_config* cfg, int device_id, uam_env** out)
                 if (grid_many3(e) <= e->many3_resident_blocks) break;
                 e->Em3 = 0;
             }
+            /* the spawn wave (a fourth wave per block that draws respawns ahead of the sweep): plain step, ownship batches of
+             * at least four steps (the record of step k + 1 is then final during step k), and only while the grid stays
+             * resident in one round with the extra wave and its mailbox */
+            if (e->Em3 > 0 && cfg->dynamics != UAM_DYN_RANDINTRUDER && !e->hold_sh && 64 / e->Em3 >= 4 &&
+                !(getenv("UAMENV_SPAWN_WAVE") && atoi(getenv("UAMENV_SPAWN_WAVE")) == 0)) {      /* development override */
+                per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, many3_fn(e), e->Tm3 + 192, lds_many3(e) + lds_many3_spawn(e)) != hipSuccess) per_cu = 0;
+                e->many3_spawn = grid_many3(e) <= per_cu * e->num_cus;
+            }
         }
         if (getenv("UAMENV_DEBUG"))
             fprintf(stderr, "[uamenv] looped kernel: grid %d, resident blocks: ownship-wave flavour %d, three-wave form %d, "
-                    "no-ownship-wave flavour %d; three-wave geometry: %d envs, %d sweeping threads per block, grid %d\n", grid_many(e, 1),
+                    "no-ownship-wave flavour %d; three-wave geometry: %d envs, %d sweeping threads per block, grid %d, spawn wave %d\n", grid_many(e, 1),
                     e->many_resident_blocks, e->many3_resident_blocks, e->many4_resident_blocks, e->Em3, e->Tm3,
-                    e->Em3 ? grid_many3(e) : 0);
+                    e->Em3 ? grid_many3(e) : 0, (int)e->many3_spawn);
         if (const char* od = getenv("UAMENV_OBS_DIRECT")) e->many_obs_direct = atoi(od);   /* development override */
     }
     if (!rc && hipEventCreate(&e->ev0) != hipSuccess) rc = fail(UAM_EIO, "hipEventCreate failed");
@@ -746,6 +758,8 @@ static inline size_t lds_many3(const uam_env* e)
     return (size_t)(2 * J + 1) * e->Em3 * 48 + (size_t)e->Em3 * 16 + (size_t)e->Tm3 * 32 * (e->hold_sh ? 6 : 4) + 16;      /* + the reset handshake word */
 }
 static inline int grid_many3(const uam_env* e) { return (e->cfg.num_envs + e->Em3 - 1) / e->Em3; }
+/* ... and the spawn wave's mailbox behind it: two halves of [T][4] float4 and of [T] tags */
+static inline size_t lds_many3_spawn(const uam_env* e) { return (size_t)e->Tm3 * 128 + (size_t)e->Tm3 * 8; }
 
 /* the same with the lane-group width a template parameter (full quads, normalised observation on the 16-byte path,
  * discrete-9 / continuous step): N = 16, 32 or 64 */
@@ -809,8 +823,10 @@ static void launch_many(const uam_env* e, UamParams p, hipStream_t st)
     p.obs_direct = e->many_obs_direct;
     const bool m3 = use_many3(e, p, fl);
     if (m3) p.E = e->Em3;
-    dim3 grid(m3 ? grid_many3(e) : grid_many(e, fl)), block(m3 ? e->Tm3 + 128 : many_threads(e, fl));
-    const size_t lds = m3 ? lds_many3(e) : lds_many(e, fl, p.obs_vec != 0);
+    const bool spw = m3 && e->many3_spawn && p.many_policy < 0;      /* (a policy inside the launch finishes record k + 1 between the barriers of step k) */
+    p.spawn_wave = spw ? 1 : 0;
+    dim3 grid(m3 ? grid_many3(e) : grid_many(e, fl)), block(m3 ? e->Tm3 + 128 + (spw ? 64 : 0) : many_threads(e, fl));
+    const size_t lds = m3 ? lds_many3(e) + (spw ? lds_many3_spawn(e) : 0) : lds_many(e, fl, p.obs_vec != 0);
 #if UAM_STAMP
     if (fl == 1) {   /* development build: per-phase s_memtime sums of every sweeping wave, averaged and printed per launch */
         const int nw = m3 ? grid_many3(e) * (e->Tm3 / 64) : grid_many(e, 1) * (e->Tm / 64);

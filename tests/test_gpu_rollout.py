@@ -67,6 +67,42 @@ def test_rollout_keeps_every_observation(uamenv, variant, B, N, K, R, looped):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("variant,B,N,K", [
+    ("continuous", 8192, 32, 420),      # BASELINE config 4's per-GPU shard: 8 envs per block, spawn wave, 8 steps per ownship pass
+    ("discrete9", 4096, 8, 400),        # 4 envs per block, 16 steps per ownship pass
+    ("mcts", 2048, 16, 300),            # raw rows, pair actions
+    ("continuous", 16384, 32, 260),     # two sweeping waves per block: no room for a spawn wave
+    ("discrete9", 1000, 64, 250),       # partial last block
+])
+def test_long_closed_loop_tape_through_the_looped_kernel(uamenv, variant, B, N, K):
+    """Hundreds of steps in ONE launch from a tape that a goal-seeking closed loop recorded on a twin handle: goals, NMACs,
+    conflicts, resets and the respawns around them all fall inside the launch — the paths where the looped kernel's
+    helper waves run ahead of the sweep on records that a reset replaces (ownship wave) or draw respawns for a step that
+    a reset makes obsolete (spawn wave).  Everything must equal the twin's K separate steps bit for bit."""
+    import torch
+    a = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=77)
+    b = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, seed=77)
+    a.reset(); b.reset()
+    dev = a.device
+    assert a.rollout_kernel(K) == "uam_sweep_many3_kernel" and a.steps_per_launch(K) == K
+    tape, want_r, want_d, want_i = [], [], [], []
+    for k in range(K):
+        act = b.policy_actions("goal", seed=k)
+        o, r, d, i = b.step(act)
+        tape.append(act.clone()); want_r.append(r.clone()); want_d.append(d.view(torch.uint8).clone()); want_i.append(i.codes.clone())
+    tape = torch.stack(tape).contiguous()
+    obs = torch.full((2, B, a.obs_dim), float("nan"), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, B), dtype=torch.float32, device=dev)
+    done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    a.rollout_into(tape, rew, done, info, obs)
+    assert torch.equal(rew, torch.stack(want_r)) and torch.equal(done, torch.stack(want_d)) and torch.equal(info, torch.stack(want_i))
+    assert torch.equal(obs[(K - 1) % 2], o)
+    pu.compare_states(a.get_state(), b.get_state(), "after the long rollout")
+    assert int(done.sum()) > B // 8, "too few episode ends inside the launch: %d" % int(done.sum())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("variant,precision,B,N,K,R,one_launch", [
     ("discrete9", "exact", 4096, 32, 40, 3, True),      # resets inside the launch (goal-seeking tape: episodes end)
     ("continuous", "f32", 1000, 8, 9, 9, True),
