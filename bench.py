@@ -397,6 +397,56 @@ def _planner_run(torch, uamenv, B, N, variant, model, what, reps):
             "agent_loop": "a plan every 5th env step (the loop of Agent.py / Agent_RandInt.py), %d steps, host-timed" % steps}
 
 
+def goal_policy_extra(ctx, args, variant):
+    """SURVEY 8d asks for both action regimes.  `value` is the random-action tape (episodes almost never end: the
+    respawn-light steady state); this is the closed loop with the library's device-side goal-seeking heuristic (turn
+    toward the goal, full throttle) choosing a FRESH action before every step from the state the previous step left —
+    a policy launch and a step launch per step, queued by uam_rollout_policy, no Python between them — which brings
+    goals, NMACs, conflicts and auto-resets (32 spawns each) into the timed steps.  An extra: never `value`."""
+    torch = ctx.torch
+    import uamenv
+    B, N, K = args.batch, args.intruders, 32
+    env = uamenv.BatchedSingleAircraftEnv(B, N, variant=variant, rng=args.rng, precision=args.precision, seed=0,
+                                          auto_reset=True, device=ctx.local_rank, fuse_rollout="never")
+    dev = env.device
+    env.reset()
+    obs = torch.empty((1, B, env.obs_dim), dtype=torch.float32, device=dev)
+    rew = torch.empty((K, B), dtype=torch.float32, device=dev)
+    done = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    info = torch.empty((K, B), dtype=torch.uint8, device=dev)
+    two = env.cfg.action_mode in (1, 4)
+    acts = torch.empty((K, B, 2) if two else (K, B), dtype=torch.float32 if env.cfg.action_mode in (2, 4) else torch.int32, device=dev)
+
+    def chunk():
+        env.rollout_policy(K, kind="goal", seed=3, rew_out=rew, done_out=done, info_out=info, obs_out=obs, actions_out=acts)
+
+    for _ in range(10):        # 320 steps: goals start to be reached after ~150
+        chunk()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    times, ends = [], 0
+    for _ in range(5):
+        e0.record()
+        for _ in range(8):
+            chunk()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) / (8 * K))
+        ends += int(done.sum().item())
+    ms = median(times)
+    launches = int(env.policy_steps_per_launch(K))
+    env.close()
+    return {"policy": "goal-seeking heuristic on the device, a fresh action before every step (uam_rollout_policy)",
+            "value": B / (ms * 1e-3), "ms_per_step": ms, "reps_ms_per_step": times,
+            "launches_per_step": "one policy launch + one step launch" if launches == 1 else "%d steps per launch" % launches,
+            "episode_ends_per_env_step": ends / float(5 * K * B),
+            "roofline_frac": env_step_bytes(N) * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
+def env_step_bytes(N):
+    return 40 * N + 150
+
+
 def copy_ms(torch, dev, nbytes, iters):
     """Plain device copies that move `nbytes` in total (half read, half written): the practical HBM ceiling.  Two
     kernels: the library's own hand-written copy (uam_bench_copy: one 16-byte element per thread, the float4 copy
@@ -425,6 +475,26 @@ def copy_ms(torch, dev, nbytes, iters):
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / iters)
     return out[0], out[1]
+
+
+def walk_gbs(torch, dev, stream_bytes, iters):
+    """GB/s of the library's bare six-stream walk (uam_bench_walk: 4 reads, 2 in-place writes) at `stream_bytes` per stream."""
+    from uamenv import _capi as capi
+    stream_bytes = stream_bytes // 16 * 16
+    spacing = stream_bytes + (2 << 20)          # separate hipMallocs of the arrays land size + 2 MiB apart
+    buf = torch.empty((3 * spacing + stream_bytes,), dtype=torch.uint8, device=dev)
+    buf.zero_()
+    L = capi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        capi.check(L.uam_bench_walk(dev.index or 0, buf.data_ptr(), 4, 2, stream_bytes, spacing, st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        capi.check(L.uam_bench_walk(dev.index or 0, buf.data_ptr(), 4, 2, stream_bytes, spacing, st))
+    e1.record()
+    torch.cuda.synchronize()
+    return 6.0 * stream_bytes / (e0.elapsed_time(e1) / iters * 1e-3) / 1e9
 
 
 def hbm_resident(ctx, args, variant):
@@ -481,6 +551,11 @@ def hbm_resident(ctx, args, variant):
     torch.cuda.empty_cache()
     cms, cms_torch = copy_ms(torch, dev, nbytes, 10)
     ach = nbytes / (ms * 1e-3) / 1e9
+    walk = None
+    try:
+        walk = walk_gbs(torch, dev, B * N * 4, 10)
+    except Exception:       # an extra of an extra
+        walk = None
     out = {"envs": B, "bytes_per_launch": nbytes, "avg_launch_ms": ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
            "copy_same_bytes_ms": cms, "frac_of_copy": cms / ms, "copy_kernel": "uam_copy_flat_kernel (library: one 16-byte element per thread, grid as large as the buffer)",
            "copy_frac_of_peak": nbytes / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS, "torch_copy_same_bytes_ms": cms_torch,
@@ -488,6 +563,13 @@ def hbm_resident(ctx, args, variant):
            "note": "frac: hipEvents around 5 x 64 queued launches (stream span / launches: includes launch gaps and the "
                    "overlapped noise launches), median; kernel_frac: hipEvents around each of 64 launches (the step "
                    "kernel alone, what rocprofv3 reports); working set 1.1 GB state+obs, not cache-resident"}
+    if walk:
+        out["walk_six_streams"] = {"achieved": walk, "frac_of_peak": walk / HBM_PEAK_GBS, "step_frac_of_walk": ach / walk,
+                                   "kernel": "uam_walk_kernel (library): four read streams of the per-intruder arrays' size, two of "
+                                             "them overwritten in place, one 16-byte element per thread — the step's fat streams "
+                                             "(px py vx vy in, px py out) with no arithmetic; arrays spaced like the handle's",
+                                   "why": "a kernel with six streams does not reach the two-stream copy's rate on this memory system "
+                                          "(profiles/r04_streams_and_placement.md)"}
     if kms:
         out["kernel_launch_ms"] = kms
         out["kernel_achieved"] = nbytes / (kms * 1e-3) / 1e9
@@ -619,6 +701,12 @@ def main():
             resident = hbm_resident(ctx, args, pvar)
         except Exception as ex:       # an extra; must never take the measurement down
             resident = {"error": repr(ex)}
+    goal = None
+    if ctx.world == 1 and not args.no_secondary and args.policy == "random":
+        try:
+            goal = goal_policy_extra(ctx, args, pvar)
+        except Exception as ex:       # an extra; must never take the measurement down
+            goal = {"error": repr(ex)}
     planner = None
     if ctx.world == 1 and not args.no_secondary and args.policy == "random" and args.rng == "philox":
         try:
@@ -699,6 +787,8 @@ def main():
                                             "registers for the chunk, so a step moves %d B/env instead of %d"
                                             % (fused["chunk"], fused["launch_bytes"] // (fused["chunk"] * res["envs_per_gpu"]),
                                                res["step_bytes"] // res["envs_per_gpu"]))
+        if goal is not None:
+            out["goal_policy"] = goal
         if planner is not None:
             out["config5_planner"] = planner
         if cpu is not None:

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("uam_policy_steps_per_launch", C.c_int32, [_P, C.c_int32]),
     ("uam_rollout_kernel", C.c_char_p, [_P, C.c_int32]),
     ("uam_bench_copy", C.c_int, [C.c_int, _P, _P, C.c_int64, _P]),
+    ("uam_bench_walk", C.c_int, [C.c_int, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P]),
     ("uam_observe", C.c_int, [_P, _P, _P]),
     ("uam_counters", C.c_int, [_P, _P, _P]),
     ("uam_nearest", C.c_int, [_P, _P, _P]),

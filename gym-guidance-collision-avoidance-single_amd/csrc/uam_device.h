@@ -3560,6 +3560,25 @@ __global__ void __launch_bounds__(256) uam_copy_flat_kernel(const uint4* __restr
     if (i < n16) dst[i] = src[i];
 }
 
+/* uam_bench_walk: thread i reads element i of R streams `spacing` bytes apart and overwrites the first W in place — the
+ * step kernel's access shape (px py vx vy in, px py out) with nothing else */
+template <int R>
+__global__ void __launch_bounds__(256) uam_walk_kernel(char* base, size_t spacing, size_t n16, int writes)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        const uint4 v = ((const uint4*)(base + (size_t)s * spacing))[i];
+        acc.x += v.x; acc.y ^= v.y; acc.z += v.z; acc.w ^= v.w;
+    }
+#pragma unroll
+    for (int s = 0; s < R; s++) {
+        if (s < writes) { acc.x += (uint32_t)s; ((uint4*)(base + (size_t)s * spacing))[i] = acc; }
+    }
+}
+
 /* built-in policies as a launch of their own (uam_policy): thread per env, state from HBM */
 __global__ void uam_policy_kernel(const UamParams p)
 {

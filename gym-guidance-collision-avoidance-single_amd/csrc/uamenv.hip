@@ -1389,6 +1389,33 @@ extern "C" int uam_bench_copy(int device, const void* src_dev, void* dst_dev, in
     return UAM_OK;
 }
 
+/* bench.py's ceiling for a kernel with the step's streams (uamenv_bench.h) */
+extern "C" int uam_bench_walk(int device, void* buf_dev, int32_t reads, int32_t writes, int64_t bytes_per_stream, int64_t spacing,
+                              void* stream)
+{
+    if (!buf_dev) return fail(UAM_EINVAL, "NULL argument");
+    if (reads < 1 || reads > 8 || writes < 1 || writes > reads) return fail(UAM_EINVAL, "uam_bench_walk needs 1 <= writes <= reads <= 8");
+    if (bytes_per_stream < 16 || (bytes_per_stream & 15) || (spacing & 15) || spacing < bytes_per_stream || ((uintptr_t)buf_dev & 15u))
+        return fail(UAM_EINVAL, "uam_bench_walk needs 16-byte aligned sizes and spacing >= bytes_per_stream");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n16 = (size_t)bytes_per_stream / 16;
+    const dim3 grid((unsigned)((n16 + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    char* b = (char*)buf_dev;
+    switch (reads) {
+    case 1: hipLaunchKernelGGL(uam_walk_kernel<1>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 2: hipLaunchKernelGGL(uam_walk_kernel<2>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 3: hipLaunchKernelGGL(uam_walk_kernel<3>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 4: hipLaunchKernelGGL(uam_walk_kernel<4>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 5: hipLaunchKernelGGL(uam_walk_kernel<5>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 6: hipLaunchKernelGGL(uam_walk_kernel<6>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    case 7: hipLaunchKernelGGL(uam_walk_kernel<7>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    default: hipLaunchKernelGGL(uam_walk_kernel<8>, grid, block, 0, st, b, (size_t)spacing, n16, (int)writes); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return UAM_OK;
+}
+
 extern "C" int64_t uam_step_bytes(const uam_env* e)
 {
     if (!e) return 0;

@@ -52,6 +52,15 @@ int32_t uam_policy_steps_per_launch(const uam_env* env, int32_t K);
  * bytes a step moves (half read, half written) as the practical ceiling of the memory system next to the 8 TB/s peak. */
 int uam_bench_copy(int device, const void* src_dev, void* dst_dev, int64_t nbytes, void* stream);
 
+/* A bare walk over several streams in lockstep, the access shape of the step kernel without its arithmetic: thread i
+ * reads its 16-byte element of `reads` arrays (array s starts at buf + s * spacing) and overwrites the first `writes` of
+ * them in place.  A kernel with six fat streams does not reach the two-stream copy's rate on this memory system
+ * (profiles/r04_streams_and_placement.md: 5.2-5.7 TB/s against 6.26 at 128 MiB per stream), so bench.py times this
+ * walk over the step's footprint (four reads, two in-place writes, the per-intruder arrays' size) as the ceiling of the
+ * HBM-resident pass.  1 <= writes <= reads <= 8; spacing >= bytes_per_stream, both multiples of 16. */
+int uam_bench_walk(int device, void* buf_dev, int32_t reads, int32_t writes, int64_t bytes_per_stream, int64_t spacing,
+                   void* stream);
+
 /* Name of the kernel a tape-driven chunk of K steps (uam_step_many / uam_rollout) runs in on this handle — the single-step
  * kernel when K launches are queued, else the K-steps-per-launch form picked for the handle's mode and batch size.  A
  * static string; "" on a bad argument.  For labels in bench lines and profiles. */

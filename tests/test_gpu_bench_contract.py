@@ -33,3 +33,6 @@ def test_bench_prints_one_contract_line():
     assert d["strong"]["variant"] == "continuous" and d["strong"]["envs_total"] == 4096 and d["strong"]["value"] > 0
     hr = r["hbm_resident"]
     assert hr["envs"] == 1 << 20 and 0 < hr["frac"] < 1 and hr["copy_same_bytes_ms"] > 0
+    # both action regimes of SURVEY 8d: the random tape is `value`, the goal-seeking closed loop rides beside it
+    gp = d["goal_policy"]
+    assert gp["value"] > 0 and gp["episode_ends_per_env_step"] > 0 and 0 < gp["roofline_frac"] < 1, gp
