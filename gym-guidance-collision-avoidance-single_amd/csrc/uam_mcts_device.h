@@ -319,29 +319,34 @@ __device__ __forceinline__ void mcts_own_traj(const MctsRng& rng, const int lane
 
 /* Section B, heading changes (6-wide model): a change at frame f only depends on the Philox stream, never on
  * positions, so all of a move's changes are settled in a PRE-PASS in three steps.  (1) Per frame, one compare per lane
- * marks the changes (bit f of chg), the change's word goes into a wave-level LDS queue (slot = running ballot rank,
- * frame-major) and the ballot and its running base are noted per frame — no arithmetic under the divergent branch.
- * (2) Every lane walks ITS OWN changes in frame order (a loop over the set bits of chg: as many trips as the busiest
- * lane has changes, ~3-4 of 10 frames at the shipped 10 %, instead of one divergent body per frame), accumulates its
+ * marks the changes (bit f of chg) and the change's word goes into the LANE'S OWN short list in LDS (UAM_MCTS_LCAP
+ * words per slot) — nothing wave-level per frame: no ballot, no rank, no table.  One wave prefix sum over the lanes'
+ * counts afterwards gives every lane the base of its run in the queue (LANE-MAJOR: a lane's changes are consecutive
+ * entries, in frame order).  (2) Every lane walks ITS OWN changes in frame order (as many trips as the busiest lane
+ * has changes, ~3-4 of 10 frames at the shipped 10 %, instead of one divergent body per frame), accumulates its
  * heading and leaves it in the queue.  (3) The queue's sincos are evaluated DENSELY (lane j takes entry j, j + 64,
  * ...: ~N entries per move instead of F sparse evaluations with ~10 % of the lanes active).  The frame loop then
- * picks its (heading, cos, sin) up by recomputing the same ballot rank.  A move with more changes than the queue
- * holds (never at the shipped rate, but possible) skips (2) and (3) and takes the slow frame loop, which evaluates
- * every change in place.  Returns the number of changes. */
+ * picks its (heading, cos, sin) up at base + (changes it has taken so far).  (Round 4: the queue used to be
+ * frame-major — slot = running ballot rank — which cost every frame a ballot, two mbcnt, two table stores and a
+ * population count in (1), two table reads and a rank per change in (2) and a ballot and a rank per frame in the frame
+ * loop; the entries' VALUES are the same, only their order in the queue differs.)  A move with more changes than the
+ * queue holds, or with a lane that has more than its list holds (never at the shipped rate, but possible), skips (2)
+ * and (3) and takes the slow frame loop, which evaluates every change in place.  Returns the number of changes. */
 #define UAM_MCTS_QCAP(K) (128 * (K))
+#define UAM_MCTS_LCAP 6                 /* change words a lane keeps per slot: P(Binomial(10, 0.1) > 6) = 9e-6 */
 
 template <int K, int PART>        /* PART 1: step (1), needs nothing of the node's state; PART 2: steps (2) and (3) */
 __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const int lane, const double* hd0, double* const qbuf,
-                                                    unsigned long long* chg, int total_in = 0)
+                                                    unsigned long long* chg, int* qbase, int total_in = 0)
 {
-    constexpr int QCAP = UAM_MCTS_QCAP(K);
+    constexpr int QCAP = UAM_MCTS_QCAP(K), LCAP = UAM_MCTS_LCAP;
     double* const qh = qbuf;              /* heading after the change */
     double* const qc = qbuf + QCAP;       /* its cosine */
     double* const qs = qbuf + 2 * QCAP;   /* its sine */
-    /* scratch of steps (1)-(2), dead before the dense sincos writes qc / qs: per (frame, slot) ballot and base */
-    unsigned long long* const tab_m = (unsigned long long*)qc;     /* [F * K] <= 63 K * 8 B */
-    int* const tab_b = (int*)(tab_m + 64 * K);                     /* [F * K]: 512 K + 256 K <= 1024 K B */
-    uint32_t* const qw = (uint32_t*)qs;                            /* [QCAP] the changes' words */
+    /* scratch of steps (1)-(2), dead before the dense sincos writes qc / qs: every lane's list of change words,
+     * [K][64][LCAP] = 1536 K B of the 2048 K B of qc + qs */
+    uint32_t* const wl = (uint32_t*)qc;
+    static_assert((size_t)K * 64 * UAM_MCTS_LCAP * 4 <= (size_t)2 * UAM_MCTS_QCAP(K) * 8, "the word lists overlay qc and qs");
     int total = total_in;
     if constexpr (PART == 1) {
         MctsParamsK& p = mcts_params();
@@ -371,23 +376,39 @@ __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const in
                     for (int k = 0; k < K; k++) {
                         const uint32_t w = hw[k][j];
                         const bool c = w < thr_l[k] || (all_in && thr_l[k] != 0u);
-                        const unsigned long long m = __ballot(c);
                         if (c) {
+                            const int have = __popcll(chg[k]);       /* changes of this slot so far: its place in my list */
+                            if (have < LCAP) wl[(k * 64 + lane) * LCAP + have] = w;
                             chg[k] |= 1ull << f;
-                            const int idx = mcts_rank(m, total);
-                            if (idx < QCAP) qw[idx] = w;
                         }
-                        tab_m[f * K + k] = m;
-                        tab_b[f * K + k] = total;
-                        total += __popcll(m);
                     }
                 }
             }
         }
+        /* how many changes the move has (a lane with more than its list holds: the slow frame loop) */
+        bool over = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int cnt = __popcll(chg[k]);
+            total += __builtin_amdgcn_readlane(wave_scan_add(cnt), 63);
+            over = over || __any(cnt > LCAP);
+        }
+        if (over) total = QCAP + 1;
         }
     }
     if constexpr (PART == 1) return total;
     if (total > QCAP) return total;
+    {   /* every lane's run in the queue: slot by slot, lanes in order (one wave prefix sum per slot; formed here, behind
+         * the ownship's trajectory, so that it is not one more value live across that section) */
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int cnt = __popcll(chg[k]);
+            const int incl = wave_scan_add(cnt);
+            qbase[k] = run + incl - cnt;
+            run += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
     mcts_wave_sync();
     {
         MctsParamsK& p = mcts_params();
@@ -396,17 +417,14 @@ __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const in
         UAM_MCTS_REPEAT(2)
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            unsigned long long pend = chg[k];
+            const int n = __popcll(chg[k]);        /* (<= LCAP here: a longer list took the slow path) */
             double hcur = hd0[k];
-            while (__any(pend != 0ull)) {
-                if (pend != 0ull) {
-                    const int f = __builtin_ctzll(pend);
-                    pend &= pend - 1ull;
-                    const int idx = mcts_rank(tab_m[f * K + k], tab_b[f * K + k]);
-                    const double ud = uam_u32d(qw[idx]) / hc_prob;
+            for (int t = 0; __any(t < n); t++) {
+                if (t < n) {
+                    const double ud = uam_u32d(wl[(k * 64 + lane) * LCAP + t]) / hc_prob;
                     const double deg = -hc_max + (hc_max - (-hc_max)) * ud;
                     hcur += deg * UAM_DEG2RAD;
-                    qh[idx] = hcur;
+                    qh[qbase[k] + t] = hcur;
                 }
             }
         }
@@ -428,8 +446,8 @@ __device__ __forceinline__ int mcts_heading_prepass(const MctsRng& rng, const in
  * is compiled in (position_sigma != 0; the shipped config has 0). */
 template <int K, int MODEL, bool PN>
 __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int lane, const double* sp, MctsState<K>& s,
-                                                const MctsOwnTraj& o, const unsigned long long* chg, const double* const qbuf,
-                                                int& fe)
+                                                const MctsOwnTraj& o, const unsigned long long* chg, const int* qbase_in,
+                                                const double* const qbuf, int& fe)
 {
     constexpr bool M4 = MODEL == UAM_MCTS_MODEL_STRAIGHT4;
     constexpr int QCAP = UAM_MCTS_QCAP(K);
@@ -447,7 +465,10 @@ __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int la
     if constexpr (PN) psig = p.position_sigma;
     uint32_t flags = 0;
     fe = F - 1;
-    int qbase = 0;
+    int qnext[K];                         /* the queue entry of my slot's next change */
+#pragma unroll
+    for (int k = 0; k < K; k++) qnext[k] = M4 ? 0 : qbase_in[k];
+    (void)qnext;
     /* without position noise a frame adds (velocity + 0.0): the same value every frame until the heading changes, so the
      * sum is formed once per velocity instead of once per frame (same operations on the same values) */
     double vxz[K], vyz[K];
@@ -475,15 +496,13 @@ __device__ __forceinline__ uint32_t mcts_frames(const MctsRng& rng, const int la
             }
             if constexpr (!M4) {
                 const bool c = (chg[k] >> f) & 1ull;
-                const unsigned long long m = __ballot(c);
                 if (c) {
-                    const int idx = mcts_rank(m, qbase);
+                    const int idx = qnext[k]++;
                     s.hd[k] = qh[idx];
                     s.vx[k] = sp[k] * qc[idx];
                     s.vy[k] = sp[k] * qs[idx];
                     if constexpr (!PN) { vxz[k] = s.vx[k] + 0.0; vyz[k] = s.vy[k] + 0.0; }
                 }
-                qbase += __popcll(m);
             }
         }
         if ((o.wallm >> f) & 1ull) { flags = 1u; fe = f; break; }                                      /* :94-96 */
@@ -558,11 +577,14 @@ __device__ __forceinline__ uint32_t mcts_move(const MctsRng& rng, const int lane
     /* the marks first: they need nothing of the node's state, whose loads (an expansion's parent comes from HBM) are
      * still in flight when the move starts */
     unsigned long long chg[K];
+    int qbase[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) qbase[k] = 0;
     int total = 0;
-    if constexpr (!M4) total = mcts_heading_prepass<K, 1>(rng, lane, nullptr, qbuf, chg);
+    if constexpr (!M4) total = mcts_heading_prepass<K, 1>(rng, lane, nullptr, qbuf, chg, qbase);
     MctsOwnTraj o;
     mcts_own_traj<K, MODEL>(rng, lane, gx, gy, a0, a1, s, nz, o);
-    if constexpr (!M4) total = mcts_heading_prepass<K, 2>(rng, lane, s.hd, qbuf, chg, total);
+    if constexpr (!M4) total = mcts_heading_prepass<K, 2>(rng, lane, s.hd, qbuf, chg, qbase, total);
     uint32_t flags;
     int fe;
     if (M4 || total <= UAM_MCTS_QCAP(K)) {
@@ -570,11 +592,11 @@ __device__ __forceinline__ uint32_t mcts_move(const MctsRng& rng, const int lane
         {   /* development: the frame loop twice, the first time on a copy of the state */
             MctsState<K> s2 = s;
             int fe2;
-            uint32_t f2 = mcts_frames<K, MODEL, PN>(rng, lane, sp, s2, o, chg, qbuf, fe2);
+            uint32_t f2 = mcts_frames<K, MODEL, PN>(rng, lane, sp, s2, o, chg, qbase, qbuf, fe2);
             asm volatile("" :: "v"(s2.x[0]), "v"(s2.y[0]), "s"(f2), "s"(fe2));
         }
 #endif
-        flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbuf, fe);
+        flags = mcts_frames<K, MODEL, PN>(rng, lane, sp, s, o, chg, qbase, qbuf, fe);
     }
     else flags = mcts_frames_slow<K, PN>(rng, lane, sp, s, o, chg, fe);
     s.ox = lane_bcast(o.ox, fe + 1); s.oy = lane_bcast(o.oy, fe + 1);
