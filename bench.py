@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 GLOBAL_BATCH = 65536    # BASELINE.json configs[2]/[3]
 N_INTRUDERS = 32
 TAPE_LEN = 64
-PMC_PROFILE = os.path.join("profiles", "r03_pmc_summary.json")
+PMC_PROFILE = "profiles/r04_pmc_summary.json"
 # measured in the build container by importing the reference; cannot be re-measured on the GPU box
 REF_PYTHON = {"env_steps_per_sec_per_core": 3.4e3, "where": "reference NumPy step() at N=32, build container "
               "(8 vCPU Xeon 2.1 GHz), one process per core; BASELINE.md §2 — measured elsewhere, not on this box"}

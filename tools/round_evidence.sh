@@ -1,10 +1,12 @@
-# Round-3 evidence beyond tools/profile_round.sh: (1) rocprofv3 durations of the looped kernels at BASELINE config 4's per-GPU
+# usage: tools/round_evidence.sh TAG   (e.g. r04; results under gpurun_out/TAGev/)
+# Per-round evidence beyond tools/profile_round.sh: (1) rocprofv3 durations of the looped kernels at BASELINE config 4's per-GPU
 # shard shapes; (2) HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, separate passes) of the RandIntruder step kernel at 65536 x 32
 # and 8192 x 64; (3) issue counters of the MCTS search kernel at 8192 x 64 and 2048 x 20.
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/r03ev; mkdir -p $O
+TAG=${1:-r04}
+O=$R/gpurun_out/${TAG}ev; mkdir -p $O
 cd /tmp
 for s in "8192 32 256 continuous" "16384 32 128 continuous" "32768 32 64 continuous" "4096 8 256 discrete9"; do
   tag=$(echo $s | tr ' ' '_')
@@ -82,3 +84,21 @@ json.dump(mc, open(O + "/mcts_pmc.json", "w"), indent=1)
 print(json.dumps(mc, indent=1)[:2500])
 PY
 cat $O/mcts_bench.jsonl
+# (4) bench lines of the other shapes and modes (no profiler): strong-scaling shards, MT19937 / exact, closed loops
+cd $R
+for B in 8192 16384 32768; do
+  python3 bench.py --no-build --scaling strong --batch $B --steps 2048 --warmup 256 --no-secondary --no-cpu-baseline --sustain-seconds 0 2>/dev/null | grep '^{' >> $O/strong_shard_shapes.jsonl
+done
+python3 bench.py --no-build --scaling strong --batch 4096 --intruders 8 --steps 2048 --warmup 256 --no-secondary --no-cpu-baseline --sustain-seconds 0 2>/dev/null | grep '^{' >> $O/strong_shard_shapes.jsonl
+python3 bench.py --no-build --rng mt19937 --precision exact --steps 2000 --warmup 200 --no-cpu-baseline --sustain-seconds 0 2>/dev/null | grep '^{' > $O/bench_mt19937_exact.jsonl
+python3 bench.py --no-build --precision exact --steps 2000 --warmup 200 --no-cpu-baseline --sustain-seconds 0 2>/dev/null | grep '^{' > $O/bench_philox_exact.jsonl
+python3 tools/bench_closed_loop.py 2>/dev/null | grep '^{' > $O/closed_loop.jsonl
+python3 - <<PY
+import json
+for l in open("$O/strong_shard_shapes.jsonl"):
+    d = json.loads(l); print("shard", d["config"]["envs_per_gpu"], d["config"]["intruders"], "us/step %.3f" % (d["ms_per_step"] * 1e3), d["config"]["launch"])
+for f in ("bench_mt19937_exact", "bench_philox_exact"):
+    d = json.loads(open("$O/%s.jsonl" % f).read().splitlines()[-1])
+    print(f, "us/step %.2f frac %.3f" % (d["ms_per_step"] * 1e3, d["roofline"]["frac"]), "fused", d.get("fused_rollout", {}).get("ms_per_step"))
+print(open("$O/closed_loop.jsonl").read())
+PY
