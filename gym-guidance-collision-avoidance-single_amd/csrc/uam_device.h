@@ -3606,14 +3606,35 @@ struct UamHerParams {
     uint8_t* done;
 };
 
+__device__ __forceinline__ float her_goal_reward_row(const UamHerParams& p, float ax, float ay, float gx, float gy)
+{
+    const double dx = (double)ax * p.W - (double)gx * p.W, dy = (double)ay * p.H - (double)gy * p.H;
+    const double d = __builtin_sqrt(dx * dx + dy * dy);      /* norm(axis=-1): plain products and sum */
+    return d < p.goal_r ? (float)p.goal_rew : (p.sparse ? (float)p.step_pen : (float)(-d / p.dense_div));
+}
+
 __global__ void __launch_bounds__(256) uam_her_goal_reward_kernel(const UamHerParams p)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.M) return;
     const float2 a = ((const float2*)p.a)[i], g = ((const float2*)p.g)[i];
-    const double dx = (double)a.x * p.W - (double)g.x * p.W, dy = (double)a.y * p.H - (double)g.y * p.H;
-    const double d = __builtin_sqrt(dx * dx + dy * dy);      /* norm(axis=-1): plain products and sum */
-    p.reward[i] = d < p.goal_r ? (float)p.goal_rew : (p.sparse ? (float)p.step_pen : (float)(-d / p.dense_div));
+    p.reward[i] = her_goal_reward_row(p, a.x, a.y, g.x, g.y);
+}
+
+/* two rows per thread with 16-byte loads and an 8-byte store (pointers 16- / 8-byte aligned: the host checks); the odd
+ * last row of an odd M falls to the thread that owns it */
+__global__ void __launch_bounds__(256) uam_her_goal_reward2_kernel(const UamHerParams p)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = 2 * t;
+    if (i >= p.M) return;
+    if (i + 1 < p.M) {
+        const float4 a = ((const float4*)p.a)[t], g = ((const float4*)p.g)[t];
+        ((float2*)p.reward)[t] = make_float2(her_goal_reward_row(p, a.x, a.y, g.x, g.y), her_goal_reward_row(p, a.z, a.w, g.z, g.w));
+    } else {
+        const float2 a = ((const float2*)p.a)[i], g = ((const float2*)p.g)[i];
+        p.reward[i] = her_goal_reward_row(p, a.x, a.y, g.x, g.y);
+    }
 }
 
 /* STAGED: the block's 256 rows are fetched with 16-byte coalesced loads into LDS first (a row is D floats,
@@ -3630,8 +3651,22 @@ __global__ void __launch_bounds__(256) uam_her_input_reward_kernel(const UamHerP
         const int total = (int)nrows * p.D;
         const float* src = p.a + row0 * p.D;           /* 16-byte aligned: base is, and 256 * D * 4 is a multiple of 16 */
         typedef float uam_f32x4 __attribute__((ext_vector_type(4)));
-        for (int c = threadIdx.x; c < (total >> 2); c += 256)
-            ((uam_f32x4*)her_lds)[c] = __builtin_nontemporal_load(&((const uam_f32x4*)src)[c]);
+        /* eight 16-byte loads of a thread in flight before the first LDS store (a load -> store loop waits for every
+         * load in turn: 5.3 TB/s; rows of the shipped width, 26 floats, are 6.5 chunks per thread) */
+        const int n4 = total >> 2;
+        for (int c0 = threadIdx.x; c0 < n4; c0 += 8 * 256) {
+            uam_f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = c0 + 256 * u;
+                v[u] = __builtin_nontemporal_load(&((const uam_f32x4*)src)[c < n4 ? c : c0]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = c0 + 256 * u;
+                if (c < n4) ((uam_f32x4*)her_lds)[c] = v[u];
+            }
+        }
         for (int c = (total & ~3) + threadIdx.x; c < total; c += 256) her_lds[c] = src[c];
         __syncthreads();
         x = her_lds + threadIdx.x * p.D;

@@ -1302,7 +1302,12 @@ extern "C" int uam_her_goal_reward(const uam_config* cfg, int device, const floa
     if (M == 0) return UAM_OK;
     HIP_TRY(hipSetDevice(device));
     p.M = M; p.a = achieved_dev; p.g = desired_dev; p.reward = reward_out_dev;
-    hipLaunchKernelGGL(uam_her_goal_reward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    if (((((uintptr_t)achieved_dev | (uintptr_t)desired_dev) & 15u) == 0) && (((uintptr_t)reward_out_dev & 7u) == 0)) {
+        const int64_t pairs = (M + 1) / 2;
+        hipLaunchKernelGGL(uam_her_goal_reward2_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(uam_her_goal_reward_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    }
     HIP_TRY(hipGetLastError());
     return UAM_OK;
 }

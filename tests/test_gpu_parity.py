@@ -688,6 +688,15 @@ def test_her_relabel_matches_reference_and_oracle(uamenv, oracle, sparse):
     assert np.array_equal(rew2.cpu().numpy(), want)
     g = uamenv.her_goal_reward(torch.from_numpy(big[:, :2].copy()).cuda(), torch.from_numpy(big[:, -2:].copy()).cuda(), sparse_reward=sparse)
     assert np.array_equal(g.cpu().numpy(), oracle.her_goal_reward(ocfg, big[:, :2], big[:, -2:]).astype(np.float32))
+    # the two-rows-per-thread kernel's odd last row, and 8-byte-aligned inputs (one row per thread)
+    odd = big[:19999]
+    want_g = oracle.her_goal_reward(ocfg, odd[:, :2], odd[:, -2:]).astype(np.float32)
+    g = uamenv.her_goal_reward(torch.from_numpy(odd[:, :2].copy()).cuda(), torch.from_numpy(odd[:, -2:].copy()).cuda(), sparse_reward=sparse)
+    assert np.array_equal(g.cpu().numpy(), want_g)
+    pad_a = torch.empty(2 * 19999 + 2, dtype=torch.float32, device="cuda"); pad_g = torch.empty_like(pad_a)
+    pad_a[2:] = torch.from_numpy(odd[:, :2].copy()).cuda().reshape(-1); pad_g[2:] = torch.from_numpy(odd[:, -2:].copy()).cuda().reshape(-1)
+    g = uamenv.her_goal_reward(pad_a[2:].view(-1, 2), pad_g[2:].view(-1, 2), sparse_reward=sparse)
+    assert np.array_equal(g.cpu().numpy(), want_g)
 
 
 # ---------------------------------------------------------------- NumPy-facing VecEnv adapter
